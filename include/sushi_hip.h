@@ -1,0 +1,108 @@
+/*
+ * include/sushi_hip.h -- C ABI of libsushi_hip.so (MI355X / gfx950 only)
+ *
+ * The reference (tp7/Sushi) has no FFI on this path: `wav.WavStream.find_substream`
+ * (wav.py:177-188) calls `cv2.matchTemplate(..., cv2.TM_SQDIFF_NORMED)` (wav.py:185) and
+ * `ndarray.argmin` (wav.py:186) in-process.  These entry points are what a ctypes binding
+ * inside a drop-in `wav.py` binds instead of `import cv2`:
+ *
+ *   sushi_hip_prepare_stream   replaces the per-call work cv2 redoes on `self.data`
+ *                              (CV_64F integral of the search image, templmatch.cpp
+ *                              common_matchTemplate) by doing it once per WavStream
+ *                              (wav.py:108-162 builds `self.data`; this runs right after).
+ *   sushi_hip_match_batch      replaces wav.py:185-186 for a whole batch of
+ *                              (pattern, window) pairs; one launch, one (index, score) per pair.
+ *
+ * Conventions: extern "C", plain pointers and sizes, no C++ or torch types.  Every pointer
+ * named *_dev is a device (HBM) pointer owned by the caller for the duration of the call's
+ * execution on `hip_stream`; nothing is retained.  `hip_stream` is a hipStream_t passed as
+ * void* (NULL = the default stream).  Calls are asynchronous with respect to the host and
+ * return 0 or a negative SUSHI_HIP_E* code; no exception crosses the boundary.
+ */
+#ifndef SUSHI_HIP_H
+#define SUSHI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUSHI_HIP_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define SUSHI_HIP_API __attribute__((visibility("default")))
+#else
+#define SUSHI_HIP_API
+#endif
+
+/* error codes */
+#define SUSHI_HIP_OK 0
+#define SUSHI_HIP_EINVAL (-1)    /* bad argument (null pointer, negative size, unknown dtype/method/variant) */
+#define SUSHI_HIP_EALIGN (-2)    /* a device pointer is not aligned as documented */
+#define SUSHI_HIP_ELAUNCH (-3)   /* the HIP runtime rejected a launch / memset (see hipGetLastError) */
+#define SUSHI_HIP_ENOSPACE (-4)  /* workspace too small */
+#define SUSHI_HIP_ENODEV (-5)    /* no gfx950 device visible */
+
+/* sample types of WavStream.data (wav.py:109: 'uint8' or 'float32') */
+#define SUSHI_HIP_U8 0
+#define SUSHI_HIP_F32 1
+
+/* matching methods.  0 is what the reference uses (wav.py:185). */
+#define SUSHI_HIP_SQDIFF_NORMED 0
+
+/* One search = one call of WavStream.find_substream (wav.py:177-188) after its window
+ * arithmetic: `pattern` is src.data[0, tmpl_off : tmpl_off + tmpl_len] and `search_source`
+ * is dst.data[0, win_start : win_start + n_pos + tmpl_len - 1]; n_pos = result.shape[1].
+ * first_tile = sum over previous searches of ceil(n_pos / tile_positions(variant)). */
+typedef struct SushiHipSearch {
+    int64_t tmpl_off;
+    int64_t win_start;
+    int32_t tmpl_len;
+    int32_t n_pos;
+    int32_t first_tile;
+    int32_t reserved;
+} SushiHipSearch;
+
+SUSHI_HIP_API int sushi_hip_abi_version(void);
+SUSHI_HIP_API const char* sushi_hip_strerror(int code);
+
+/* 0 if a gfx950 device is current, SUSHI_HIP_ENODEV otherwise. */
+SUSHI_HIP_API int sushi_hip_device_ok(void);
+
+/* Kernel variants differ only in how many result positions one workgroup owns. */
+SUSHI_HIP_API int sushi_hip_variant_count(void);
+SUSHI_HIP_API int sushi_hip_variant_tile_positions(int variant);
+
+/* Stream preparation.  raw_dev: n samples of `dtype` (the row WavStream.data[0]).
+ * Outputs: xc_dev[n] float32 = sample - centre (centre = 0.5 for float32 data in [0,1],
+ * 128 for uint8), s1_dev[n+1] / s2_dev[n+1] float64 exclusive prefix sums of xc and xc^2.
+ * xc_dev must be 16-byte aligned.  ws_dev: scratch of sushi_hip_prepare_workspace_bytes(n). */
+SUSHI_HIP_API size_t sushi_hip_prepare_workspace_bytes(int64_t n);
+SUSHI_HIP_API double sushi_hip_centre(int dtype);
+SUSHI_HIP_API int sushi_hip_prepare_stream(const void* raw_dev, int dtype, int64_t n,
+                             float* xc_dev, double* s1_dev, double* s2_dev,
+                             void* ws_dev, size_t ws_bytes, void* hip_stream);
+
+/* Batched template match + arg-minimum.
+ *   dst_* : prepared search stream (the WavStream find_substream is called on), dst_len samples
+ *   src_* : prepared stream the patterns are slices of, src_len samples
+ *   centre: the value subtracted by sushi_hip_prepare_stream for these streams' dtype
+ *   searches_dev[n_search], ordered by first_tile; n_tiles = total tile count
+ *   keys_ws_dev[n_search] : uint64 scratch
+ *   out_idx_dev[n_search]   = result.argmin(axis=1)[0]        (wav.py:186)
+ *   out_score_dev[n_search] = result[0][min_idx], float32     (wav.py:188)
+ * Preconditions checked by the caller: 1 <= tmpl_len, 1 <= n_pos, tmpl_off + tmpl_len <= src_len,
+ * win_start + n_pos + tmpl_len - 1 <= dst_len. */
+SUSHI_HIP_API int sushi_hip_match_batch(const float* dst_xc_dev, const double* dst_s1_dev, const double* dst_s2_dev, int64_t dst_len,
+                          const float* src_xc_dev, const double* src_s1_dev, const double* src_s2_dev, int64_t src_len,
+                          double centre, int method,
+                          const SushiHipSearch* searches_dev, int n_search, int n_tiles, int variant,
+                          uint64_t* keys_ws_dev, int32_t* out_idx_dev, float* out_score_dev,
+                          void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUSHI_HIP_H */

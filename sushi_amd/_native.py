@@ -1,0 +1,79 @@
+"""ctypes binding of libsushi_hip.so (C ABI: include/sushi_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, the product path raises.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+from .common import SushiError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsushi_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sushi_hip.h")
+
+# dtype codes (include/sushi_hip.h)
+U8, F32 = 0, 1
+SQDIFF_NORMED = 0
+
+# struct SushiHipSearch, 32 bytes
+SEARCH_DTYPE = np.dtype([("tmpl_off", "<i8"), ("win_start", "<i8"), ("tmpl_len", "<i4"),
+                         ("n_pos", "<i4"), ("first_tile", "<i4"), ("reserved", "<i4")], align=True)
+assert SEARCH_DTYPE.itemsize == 32
+
+_lib = None
+
+
+class NativeError(SushiError):
+    pass
+
+
+def declared_symbols():
+    """Every function include/sushi_hip.h declares (used by the CPU-side export test)."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"SUSHI_HIP_API\s+[\w\s\*]+?\b(sushi_hip_\w+)\s*\(", text)))
+
+
+def lib():
+    """Load (once) and type the library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError("libsushi_hip.so is not built (%s); run `python -m sushi_amd.build` -- "
+                          "there is no CPU fallback for the matching path" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i64, ci, dbl, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+    L.sushi_hip_abi_version.restype = ci
+    L.sushi_hip_strerror.restype = ctypes.c_char_p
+    L.sushi_hip_strerror.argtypes = [ci]
+    L.sushi_hip_device_ok.restype = ci
+    L.sushi_hip_variant_count.restype = ci
+    L.sushi_hip_variant_tile_positions.restype = ci
+    L.sushi_hip_variant_tile_positions.argtypes = [ci]
+    L.sushi_hip_prepare_workspace_bytes.restype = sz
+    L.sushi_hip_prepare_workspace_bytes.argtypes = [i64]
+    L.sushi_hip_centre.restype = dbl
+    L.sushi_hip_centre.argtypes = [ci]
+    L.sushi_hip_prepare_stream.restype = ci
+    L.sushi_hip_prepare_stream.argtypes = [vp, ci, i64, vp, vp, vp, vp, sz, vp]
+    L.sushi_hip_match_batch.restype = ci
+    L.sushi_hip_match_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp, i64, dbl, ci, vp, ci, ci, ci, vp, vp, vp, vp]
+    if L.sushi_hip_abi_version() != 1:
+        raise NativeError("libsushi_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().sushi_hip_strerror(rc).decode()
+        raise NativeError("%s failed: %s (%d)" % (what, msg, rc))
+
+
+def variant_tiles():
+    L = lib()
+    return [L.sushi_hip_variant_tile_positions(v) for v in range(L.sushi_hip_variant_count())]

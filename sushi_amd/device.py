@@ -1,0 +1,149 @@
+"""Device-side state and launches.  PyTorch owns HBM allocations and HIP streams (plumbing);
+all arithmetic is in libsushi_hip.so.
+
+* ``DeviceStream``  -- the HBM mirror of one ``WavStream.data`` row: centred float32 samples
+  and float64 prefix sums (built once by ``sushi_hip_prepare_stream``).
+* ``SearchBatch``   -- a batch of (pattern, window) descriptors resident in HBM; ``run()`` is one
+  pass of the hot path (memset + match kernel + unpack) and nothing else.
+"""
+import numpy as np
+import torch
+
+from . import _native
+from .common import SushiError
+
+_DTYPE_CODE = {np.dtype(np.uint8): _native.U8, np.dtype(np.float32): _native.F32}
+
+
+def _require_gpu(device=None):
+    if not torch.cuda.is_available():
+        raise SushiError("sushi_amd needs a ROCm GPU (MI355X / gfx950): torch.cuda.is_available() is False "
+                         "and there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+
+def _raw_stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class DeviceStream(object):
+    """HBM-resident, match-ready form of a 1-D sample row (uint8 or float32)."""
+
+    def __init__(self, samples, device=None, keep_raw=False):
+        samples = np.ascontiguousarray(samples)
+        if samples.ndim == 2 and samples.shape[0] == 1:
+            samples = samples[0]
+        if samples.ndim != 1:
+            raise SushiError("DeviceStream expects a 1-D (or (1, N)) sample array")
+        if samples.dtype not in _DTYPE_CODE:
+            raise SushiError("Unknown sample type of WAV stream, must be uint8 or float32")
+        if samples.shape[0] < 1:
+            raise SushiError("empty sample array")
+        self.device = _require_gpu(device)
+        self.dtype = samples.dtype
+        self.dtype_code = _DTYPE_CODE[samples.dtype]
+        self.n = int(samples.shape[0])
+        L = _native.lib()
+        _native.check(L.sushi_hip_device_ok(), "device check")
+        self.centre = float(L.sushi_hip_centre(self.dtype_code))
+        with torch.cuda.device(self.device):
+            raw = torch.from_numpy(samples).to(self.device, non_blocking=False)
+            self.xc = torch.empty(self.n, dtype=torch.float32, device=self.device)
+            self.s1 = torch.empty(self.n + 1, dtype=torch.float64, device=self.device)
+            self.s2 = torch.empty(self.n + 1, dtype=torch.float64, device=self.device)
+            ws_bytes = int(L.sushi_hip_prepare_workspace_bytes(self.n))
+            ws = torch.empty(max(ws_bytes // 8, 2), dtype=torch.float64, device=self.device)
+            rc = L.sushi_hip_prepare_stream(raw.data_ptr(), self.dtype_code, self.n,
+                                            self.xc.data_ptr(), self.s1.data_ptr(), self.s2.data_ptr(),
+                                            ws.data_ptr(), ws.numel() * 8, _raw_stream(self.device))
+            _native.check(rc, "sushi_hip_prepare_stream")
+            torch.cuda.current_stream(self.device).synchronize()   # ws/raw may be freed now
+        self.raw = raw if keep_raw else None
+
+    def nbytes(self):
+        return self.xc.numel() * 4 + (self.s1.numel() + self.s2.numel()) * 8
+
+
+def choose_variant(n_pos, total_waves_wanted=4096):
+    """Largest tile whose grid still gives the chip (256 CUs x 4 SIMDs) a few waves per SIMD."""
+    tiles = _native.variant_tiles()
+    waves = [1, 4, 4]
+    n_pos = np.asarray(n_pos, dtype=np.int64)
+    best = 0
+    for v, tp in enumerate(tiles):
+        nt = int(((n_pos + tp - 1) // tp).sum())
+        if nt * waves[v] >= total_waves_wanted:
+            best = v
+    return best
+
+
+class SearchBatch(object):
+    """Descriptors of a batch of searches, resident in HBM, plus the output buffers.
+
+    tmpl_off / tmpl_len : pattern = src row [tmpl_off, tmpl_off + tmpl_len)
+    win_start / n_pos   : search_source = dst row [win_start, win_start + n_pos + tmpl_len - 1)
+    (exactly the two arrays wav.py:184-185 hands to cv2.matchTemplate)
+    """
+
+    def __init__(self, dst, src, tmpl_off, tmpl_len, win_start, n_pos, variant=None):
+        if dst.device != src.device:
+            raise SushiError("dst and src streams live on different devices")
+        if dst.dtype != src.dtype:
+            raise SushiError("pattern and stream sample types differ (cv2.matchTemplate asserts equal types)")
+        self.dst, self.src = dst, src
+        tmpl_off = np.asarray(tmpl_off, dtype=np.int64).reshape(-1)
+        tmpl_len = np.asarray(tmpl_len, dtype=np.int64).reshape(-1)
+        win_start = np.asarray(win_start, dtype=np.int64).reshape(-1)
+        n_pos = np.asarray(n_pos, dtype=np.int64).reshape(-1)
+        n = tmpl_off.shape[0]
+        if not (tmpl_len.shape[0] == win_start.shape[0] == n_pos.shape[0] == n) or n == 0:
+            raise SushiError("descriptor arrays must be non-empty and of equal length")
+        if (tmpl_len < 1).any():
+            raise SushiError("empty pattern")
+        if (n_pos < 1).any():
+            raise SushiError("pattern is longer than the search window (cv2.error in the reference)")
+        if (tmpl_off < 0).any() or (tmpl_off + tmpl_len > src.n).any():
+            raise SushiError("pattern slice outside the source stream")
+        if (win_start < 0).any() or (win_start + n_pos + tmpl_len - 1 > dst.n).any():
+            raise SushiError("search window outside the destination stream")
+        if (n_pos > 0x7fffffff - 65536).any() or (tmpl_len > 0x7fffffff - 65536).any():
+            raise SushiError("search too large")
+        self.n = n
+        self.variant = choose_variant(n_pos) if variant is None else int(variant)
+        tp = _native.variant_tiles()[self.variant]
+        tiles = (n_pos + tp - 1) // tp
+        first = np.zeros(n, dtype=np.int64)
+        np.cumsum(tiles[:-1], out=first[1:])
+        self.n_tiles = int(tiles.sum())
+        if self.n_tiles > 0x7fffffff:
+            raise SushiError("too many tiles in one batch")
+        desc = np.zeros(n, dtype=_native.SEARCH_DTYPE)
+        desc["tmpl_off"], desc["win_start"] = tmpl_off, win_start
+        desc["tmpl_len"], desc["n_pos"], desc["first_tile"] = tmpl_len, n_pos, first
+        self.host_desc = desc
+        # algorithmic work of this batch: 2*P*M flop, 4*(P+M-1)+4*M+8 bytes per search
+        self.flops = float((2.0 * n_pos.astype(np.float64) * tmpl_len.astype(np.float64)).sum())
+        self.algorithmic_bytes = float((4.0 * (n_pos + tmpl_len - 1) + 4.0 * tmpl_len + 8.0).sum())
+        dev = dst.device
+        with torch.cuda.device(dev):
+            self.desc = torch.from_numpy(desc.view(np.uint8).reshape(-1)).to(dev)
+            self.keys = torch.empty(n, dtype=torch.int64, device=dev)
+            self.out_idx = torch.empty(n, dtype=torch.int32, device=dev)
+            self.out_score = torch.empty(n, dtype=torch.float32, device=dev)
+
+    def run(self, hip_stream=None):
+        """One pass of the hot path over this batch (asynchronous)."""
+        L = _native.lib()
+        dst, src = self.dst, self.src
+        st = _raw_stream(dst.device) if hip_stream is None else hip_stream
+        rc = L.sushi_hip_match_batch(dst.xc.data_ptr(), dst.s1.data_ptr(), dst.s2.data_ptr(), dst.n,
+                                     src.xc.data_ptr(), src.s1.data_ptr(), src.s2.data_ptr(), src.n,
+                                     dst.centre, _native.SQDIFF_NORMED,
+                                     self.desc.data_ptr(), self.n, self.n_tiles, self.variant,
+                                     self.keys.data_ptr(), self.out_idx.data_ptr(), self.out_score.data_ptr(), st)
+        _native.check(rc, "sushi_hip_match_batch")
+        return self.out_idx, self.out_score
+
+    def results(self):
+        """(idx int32 ndarray, score float32 ndarray) -- synchronises."""
+        return self.out_idx.cpu().numpy(), self.out_score.cpu().numpy()

@@ -1,0 +1,72 @@
+"""Sharding the event batch across the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The path shards by event: every search reads only the two (replicated) streams, so ranks share
+nothing on the data path.  Each rank takes a contiguous block of the (time-sorted) searches --
+neighbouring events overlap in the destination stream, which keeps a rank's working set local --
+and the only collective is one all-gather of the per-event (index, score) pairs: 8 bytes per event.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, rank, world_size):
+    """Contiguous block [lo, hi) of rank `rank`; sizes differ by at most one."""
+    base, rem = divmod(n_items, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def max_shard(n_items, world_size):
+    return (n_items + world_size - 1) // world_size
+
+
+def pack_results(idx, score, pad_to):
+    """(idx int32[n], score float32[n]) -> int32[pad_to, 2] (score bits in column 1); padding = -1."""
+    n = idx.shape[0]
+    out = torch.full((pad_to, 2), -1, dtype=torch.int32, device=idx.device)
+    out[:n, 0] = idx
+    out[:n, 1] = score.view(torch.int32)
+    return out
+
+
+def gather_results(idx, score, n_total, group=None):
+    """All ranks call this with their local block's results; every rank gets the full
+    (idx int32[n_total], score float32[n_total]) in global search order."""
+    world = dist.get_world_size(group)
+    pad = max_shard(n_total, world)
+    packed = pack_results(idx, score, pad)
+    full = torch.empty((world * pad, 2), dtype=torch.int32, device=packed.device)
+    dist.all_gather_into_tensor(full, packed, group=group)
+    full = full.view(world, pad, 2)
+    pieces_i, pieces_s = [], []
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, r, world)
+        pieces_i.append(full[r, :hi - lo, 0])
+        pieces_s.append(full[r, :hi - lo, 1])
+    return torch.cat(pieces_i), torch.cat(pieces_s).view(torch.float32)
+
+
+class ShardedSearch(object):
+    """Runs this rank's block of a global descriptor list and gathers everyone's results.
+
+    `make_batch(lo, hi)` must return an object with `.run()` -> (idx, score) device tensors for
+    searches [lo, hi) (a `SearchBatch` on the GPU; the CPU tests pass a stand-in)."""
+
+    def __init__(self, n_total, make_batch, group=None):
+        self.n_total = n_total
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.lo, self.hi = shard_bounds(n_total, self.rank, self.world)
+        self.batch = make_batch(self.lo, self.hi) if self.hi > self.lo else None
+
+    def run(self):
+        if self.batch is not None:
+            idx, score = self.batch.run()
+        else:
+            idx = torch.empty(0, dtype=torch.int32)
+            score = torch.empty(0, dtype=torch.float32)
+        if self.world == 1:
+            return idx, score
+        return gather_results(idx, score, self.n_total, self.group)

@@ -1,0 +1,252 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  All tests need an MI355X.
+
+Tolerances (BASELINE.json north_star):
+  * uint8 streams  : every sum is an exact integer on both sides -> index AND float32 score bit-exact.
+  * float32 streams: |score - oracle| <= 1e-4 * max(oracle, 1e-3); index equal, or -- when two
+    positions are tied to within cv2's own float32 quantum of corr -- the oracle's score at our
+    index is within 2e-7 of the oracle's minimum.  Planted-offset cases additionally demand the
+    shift to be within +-1 sample of the planted one.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCORE_RTOL = 1e-4
+SCORE_FLOOR = 1e-3
+TIE_ATOL = 2e-7
+
+
+def _check_f32(res_row, idx, score):
+    o_idx = int(res_row.argmin())
+    o_score = float(res_row[o_idx])
+    assert abs(float(score) - o_score) <= SCORE_RTOL * max(o_score, SCORE_FLOOR), (score, o_score)
+    if int(idx) != o_idx:
+        assert abs(float(res_row[int(idx)]) - o_score) <= TIE_ATOL, (idx, o_idx, res_row[int(idx)], o_score)
+
+
+def _check_u8(res_row, idx, score):
+    o_idx = int(res_row.argmin())
+    assert int(idx) == o_idx
+    assert np.float32(score).view(np.uint32) == np.float32(res_row[o_idx]).view(np.uint32)
+
+
+def _run_batch(dst_row, src_row, offs, lens, wstart, npos, variant=None):
+    from sushi_amd.device import DeviceStream, SearchBatch
+    dst = DeviceStream(dst_row)
+    src = DeviceStream(src_row)
+    b = SearchBatch(dst, src, offs, lens, wstart, npos, variant=variant)
+    b.run()
+    return b.results()
+
+
+def test_extension_is_loaded_and_device_is_gfx950():
+    from sushi_amd import _native
+    L = _native.lib()
+    assert L.sushi_hip_device_ok() == 0
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint8])
+@pytest.mark.parametrize("n", [1, 5, 4095, 4096, 4097, 300001, 5000000])
+def test_prepare_stream(dtype, n):
+    from sushi_amd.device import DeviceStream
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, 256, n, dtype=np.uint8) if dtype == np.uint8 else rng.random(n, dtype=np.float32)
+    d = DeviceStream(x)
+    c = 128.0 if dtype == np.uint8 else 0.5
+    xc = (x.astype(np.float32) - np.float32(c))
+    assert (d.xc.cpu().numpy() == xc).all()
+    s1 = np.concatenate(([0.0], np.cumsum(xc.astype(np.float64))))
+    s2 = np.concatenate(([0.0], np.cumsum(xc.astype(np.float64) ** 2)))
+    g1, g2 = d.s1.cpu().numpy(), d.s2.cpu().numpy()
+    if dtype == np.uint8:
+        assert (g1 == s1).all() and (g2 == s2).all()          # integers: exact in any summation order
+    else:
+        np.testing.assert_allclose(g1, s1, rtol=0, atol=1e-9 * max(1.0, np.abs(s1).max()))
+        np.testing.assert_allclose(g2, s2, rtol=1e-13, atol=1e-9)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [np.float32, np.uint8])
+@pytest.mark.parametrize("L,M", [(1, 1), (40, 40), (1500, 100), (3000, 700), (20000, 1537), (9000, 4800)])
+def test_random_search_vs_oracle(oracle, variant, dtype, L, M):
+    rng = np.random.default_rng(L * 31 + M + variant)
+    if dtype == np.uint8:
+        dst = rng.integers(0, 256, L + 77, dtype=np.uint8)
+        src = rng.integers(0, 256, M + 13, dtype=np.uint8)
+    else:
+        dst = rng.random(L + 77, dtype=np.float32)
+        src = rng.random(M + 13, dtype=np.float32)
+    ws, to = 41, 7
+    P = L - M + 1
+    idx, score = _run_batch(dst, src, [to], [M], [ws], [P], variant)
+    res = oracle.match_template_direct(dst[ws:ws + L], src[to:to + M])[0]
+    (_check_u8 if dtype == np.uint8 else _check_f32)(res, idx[0], score[0])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint8])
+def test_ragged_batch_all_variants(oracle, dtype):
+    """One launch, many searches of very different sizes (incl. M = 1, P = 1, multi-tile P)."""
+    rng = np.random.default_rng(11)
+    n_dst, n_src = 120000, 30000
+    if dtype == np.uint8:
+        dst = rng.integers(0, 256, n_dst, dtype=np.uint8)
+        src = rng.integers(0, 256, n_src, dtype=np.uint8)
+    else:
+        dst = (rng.standard_normal(n_dst) * 0.2 + 0.5).clip(0, 1).astype(np.float32)
+        src = (rng.standard_normal(n_src) * 0.2 + 0.5).clip(0, 1).astype(np.float32)
+    # plant a few real matches
+    for k in range(6):
+        a, m = 3000 * k + 17, 400 + 250 * k
+        src[a:a + m] = dst[50000 + 1111 * k: 50000 + 1111 * k + m]
+    offs, lens, wst, npos = [], [], [], []
+    for k in range(40):
+        m = int(rng.choice([1, 2, 31, 32, 33, 100, 513, 1024, 2500, 6000]))
+        p = int(rng.choice([1, 2, 1023, 1024, 1025, 4097, 20000, 40000]))
+        to = int(rng.integers(0, n_src - m))
+        ws = int(rng.integers(0, n_dst - (p + m - 1)))
+        offs.append(to); lens.append(m); wst.append(ws); npos.append(p)
+    for k in range(6):
+        a, m = 3000 * k + 17, 400 + 250 * k
+        offs.append(a); lens.append(m); wst.append(30000); npos.append(60000)
+    refs = [oracle.match_template(dst[w:w + p + m - 1], src[o:o + m])[0]
+            for o, m, w, p in zip(offs, lens, wst, npos)]
+    for variant in (0, 1, 2, None):
+        idx, score = _run_batch(dst, src, offs, lens, wst, npos, variant)
+        for k, res in enumerate(refs):
+            (_check_u8 if dtype == np.uint8 else _check_f32)(res, idx[k], score[k])
+        for k in range(6):
+            assert idx[40 + k] == 20000 + 1111 * k          # planted copies found exactly
+
+
+def test_planted_copy_ties_and_degenerate(oracle):
+    rng = np.random.default_rng(1)
+    img = rng.random(30000, dtype=np.float32)
+    t = img[12345:12345 + 5000].copy()
+    idx, score = _run_batch(img, t, [0], [5000], [0], [25001])
+    assert idx[0] == 12345 and score[0] <= 1e-6
+    # exact ties (dyadic floats / uint8): first index wins, like ndarray.argmin (wav.py:186)
+    for period in ((rng.integers(0, 64, 50) / 64.0).astype(np.float32), rng.integers(0, 256, 50, dtype=np.uint8)):
+        img = np.tile(period, 400)
+        idx, score = _run_batch(img, img, [10], [120], [0], [img.shape[0] - 119])
+        assert idx[0] == 10 and score[0] == 0.0
+        idx, score = _run_batch(img, img, [10], [120], [23], [img.shape[0] - 119 - 23])
+        assert idx[0] == 37 and score[0] == 0.0             # first p with (p + 23) % 50 == 10
+    # all-zero windows -> 1.0 (never NaN), all-equal result -> index 0
+    z = np.zeros(5000, np.float32)
+    t = np.full(100, 0.25, np.float32)
+    idx, score = _run_batch(z, t, [0], [100], [0], [4901])
+    assert idx[0] == 0 and score[0] == 1.0
+    zu = np.zeros(5000, np.uint8)
+    idx, score = _run_batch(zu, zu, [0], [100], [0], [4901])
+    assert idx[0] == 0 and score[0] == 1.0
+
+
+def test_halves_identity_on_gpu(oracle):
+    """Full / left / right searches of sushi.py:450-452: each one individually matches the oracle."""
+    rng = np.random.default_rng(4)
+    dst = (rng.standard_normal(80000) * 0.2 + 0.5).clip(0, 1).astype(np.float32)
+    src = dst[20000:26001].copy() + (rng.standard_normal(6001) * 0.01).astype(np.float32)
+    k = 6001 // 2
+    offs, lens = [0, 0, k], [6001, k, 6001 - k]
+    wst, npos = [1000, 1000, 1000 + k], [60000, 60000, 60000]
+    idx, score = _run_batch(dst, src, offs, lens, wst, npos)
+    for j in range(3):
+        res = oracle.match_template(dst[wst[j]:wst[j] + npos[j] + lens[j] - 1], src[offs[j]:offs[j] + lens[j]])[0]
+        _check_f32(res, idx[j], score[j])
+    assert idx[0] == 19000 and idx[1] == 19000 and idx[2] == 19000
+
+
+@pytest.mark.parametrize("sample_type", ["uint8", "float32"])
+def test_find_substream_dropin_vs_oracle_with_clipping(oracle, sample_type):
+    """WavStream.find_substream vs the oracle's wav.py:177-188 restatement, including windows
+    clipped at both ends of the stream, negative start times and NumPy slice truncation."""
+    from sushi_amd import synth
+    from sushi_amd.wav import WavStream
+    dst_pcm = synth.make_dst_pcm(40, 12000, seed=5)
+    src_pcm = synth.make_src_pcm(dst_pcm, 18000, seed=6)       # dst time = src time + 1.5 s
+    dst = WavStream.from_samples(dst_pcm, 12000, sample_type=sample_type)
+    src = WavStream.from_samples(src_pcm, 12000, sample_type=sample_type)
+    odst = oracle.OracleWavStream(dst.data, dst.sample_rate, dst.sample_count, dst.padding_size)
+    cases = [(5.0, 7.5, 6.5, 1.5), (5.0, 7.5, 6.5, 10), (0.0, 2.0, 0.2, 10), (0.0, 1.0, -3.0, 10),
+             (36.0, 38.4, 39.5, 10), (33.0, 38.0, 45.0, 10), (10.0, 10.4, 11.5, 30), (20.0, 24.0, 3.0, 60)]
+    for (a, b, c, w) in cases:
+        pat = src.get_substream(a, b)
+        diff, t = dst.find_substream(pat, c, w)
+        rdiff, rt = odst.find_substream(pat, c, w)
+        assert isinstance(t, float)
+        if sample_type == "uint8":
+            assert t == rt and np.float32(diff) == np.float32(rdiff)
+        else:
+            assert abs(float(diff) - float(rdiff)) <= SCORE_RTOL * max(float(rdiff), SCORE_FLOOR)
+            assert abs(t - rt) <= 1.0 / 12000 + 1e-12
+    # the three searches of sushi.py:450-452 in one batched call, patterns being np.split views
+    pat = src.get_substream(12.0, 15.0)
+    left, right = np.split(pat, [pat.shape[1] // 2], axis=1)
+    off = left.shape[1] / float(src.sample_rate)
+    diffs, times = dst.find_substreams([pat, left, right], [13.5, 13.5, 13.5 + off], [10, 10, 10])
+    assert abs(times[0] - 13.5) <= 1 / 12000 + 1e-9 and abs(times[1] - 13.5) <= 1 / 12000 + 1e-9
+    assert abs(times[2] - off - 13.5) <= 1 / 12000 + 1e-9
+    # a pattern that is NOT a view of a live stream takes the upload path and gives the same answer
+    d2, t2 = dst.find_substream(pat.copy(), 13.5, 10)
+    assert t2 == times[0] and np.float32(d2) == np.float32(diffs[0])
+    # pattern longer than the clipped window: cv2.error in the reference, SushiError here
+    from sushi_amd import SushiError
+    with pytest.raises(SushiError):
+        dst.find_substream(src.get_substream(1.0, 13.5), 39.99, 1.5)
+
+
+@pytest.mark.parametrize("sample_type", ["uint8", "float32"])
+def test_config1_global_offset_recovered(oracle, sample_type, tmp_path):
+    """BASELINE config 0: 50 events, 5-min 12 kHz streams (through real WAV files), +1.5 s offset."""
+    import os
+    from sushi_amd import synth
+    from sushi_amd.wav import WavStream
+    dst_pcm = synth.make_dst_pcm(300, 12000, seed=20260924)
+    src_pcm = synth.make_src_pcm(dst_pcm, 18000, seed=20260925)
+    pd, ps = os.path.join(tmp_path, "dst.wav"), os.path.join(tmp_path, "src.wav")
+    synth.write_wav(pd, dst_pcm, 12000)
+    synth.write_wav(ps, src_pcm, 12000)
+    dst = WavStream(pd, sample_type=sample_type)
+    src = WavStream(ps, sample_type=sample_type)
+    events = synth.make_events(50, 300, 1.5, seed=7)
+    pats = [src.get_substream(s, e) for s, e in events]
+    # sequential drop-in calls (small window around the true shift) ...
+    for (s, e), p in list(zip(events, pats))[:5]:
+        diff, t = dst.find_substream(p, s + 1.5, 1.5)
+        assert abs((t - s) - 1.5) <= 1.0 / 12000 + 1e-9
+    # ... and all 50 in one launch with the default +-10 s window, centre at the unshifted time
+    diffs, times = dst.find_substreams(pats, [s for s, _ in events], [10] * 50)
+    odst = oracle.OracleWavStream(dst.data, dst.sample_rate, dst.sample_count, dst.padding_size)
+    for k, ((s, e), p) in enumerate(zip(events, pats)):
+        assert abs((times[k] - s) - 1.5) <= 1.0 / 12000 + 1e-9
+        if k % 10 == 0:
+            rdiff, rt = odst.find_substream(p, s, 10, matcher=oracle.match_template_fft)
+            assert abs(times[k] - rt) <= 1.0 / 12000 + 1e-12
+            if sample_type == "uint8":
+                assert np.float32(diffs[k]) == np.float32(rdiff) and times[k] == rt
+            else:
+                assert abs(float(diffs[k]) - float(rdiff)) <= SCORE_RTOL * max(float(rdiff), SCORE_FLOOR)
+
+
+def test_full_size_windows_properties(oracle):
+    """BASELINE config 1 sizes (45-min streams, +-60 s => P = 1,440,001): planted offset recovered
+    on every event; a sample of events checked against the FFT oracle."""
+    from sushi_amd import synth
+    from sushi_amd.wav import WavStream
+    dst_pcm = synth.make_dst_pcm(2700, 12000, seed=1)
+    off_s = 7.25
+    src_pcm = synth.make_src_pcm(dst_pcm, int(off_s * 12000), seed=2)
+    dst = WavStream.from_samples(dst_pcm, 12000, sample_type="float32")
+    src = WavStream.from_samples(src_pcm, 12000, sample_type="float32")
+    events = synth.make_events(24, 2700, 60 + off_s, seed=3)
+    pats, centres, wins = synth.explicit_descriptors(src, dst, events, off_s, 60, seed=4)
+    diffs, times = dst.find_substreams(pats, centres, wins)
+    odst = oracle.OracleWavStream(dst.data, dst.sample_rate, dst.sample_count, dst.padding_size)
+    for k, (s, e) in enumerate(events):
+        assert abs((times[k] - s) - off_s) <= 1.0 / 12000 + 1e-9
+        assert 0.0 <= diffs[k] < 0.05
+    for k in (0, 11, 23):
+        rdiff, rt = odst.find_substream(pats[k], centres[k], wins[k], matcher=oracle.match_template_fft)
+        assert abs(times[k] - rt) <= 1.0 / 12000 + 1e-12
+        assert abs(float(diffs[k]) - float(rdiff)) <= SCORE_RTOL * max(float(rdiff), SCORE_FLOOR)

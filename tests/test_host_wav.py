@@ -1,0 +1,133 @@
+"""Host side of the drop-in WavStream (no GPU): load pipeline against the oracle's statement-for-
+statement restatement of wav.py:108-162, window arithmetic against the reference-generated golden
+vectors, error behaviour."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from sushi_amd import SushiError, synth
+from sushi_amd.wav import DownmixedWavFile, WavStream, _locate
+
+
+def _write_wav24(path, pcm24, rate, channels):
+    b = bytearray()
+    for v in np.asarray(pcm24).reshape(-1):
+        b += struct.pack('<i', int(v))[:3]
+    with open(path, 'wb') as f:
+        f.write(b'RIFF' + struct.pack('<L', 36 + len(b)) + b'WAVE')
+        f.write(b'fmt ' + struct.pack('<LHHLLHH', 16, 1, channels, rate, rate * channels * 3, channels * 3, 24))
+        f.write(b'junk' + struct.pack('<L', 3) + b'abc\0')           # odd-sized chunk to skip
+        f.write(b'data' + struct.pack('<L', len(b)))
+        f.write(bytes(b))
+
+
+@pytest.mark.parametrize("rate,channels,sample_rate,seconds", [
+    (12000, 1, 12000, 7.3), (12000, 2, 12000, 3.0), (48000, 1, 12000, 2.5), (44100, 2, 12000, 3.21),
+    (8000, 3, 12000, 1.7)])
+@pytest.mark.parametrize("sample_type", ["float32", "uint8"])
+def test_load_pipeline_matches_oracle(tmp_path, oracle, rate, channels, sample_rate, seconds, sample_type):
+    rng = np.random.default_rng(rate + channels)
+    n = int(seconds * rate)
+    pcm = (rng.standard_normal((n, channels)) * 3000).astype(np.int16)
+    path = os.path.join(tmp_path, "a.wav")
+    synth.write_wav(path, pcm if channels > 1 else pcm[:, 0], rate, channels)
+    ours = WavStream(path, sample_rate=sample_rate, sample_type=sample_type)
+    ref = oracle.load_wav_stream(path, sample_rate=sample_rate, sample_type=sample_type)
+    assert ours.sample_count == ref.sample_count and ours.padding_size == ref.padding_size
+    assert ours.sample_rate == ref.sample_rate and ours.duration_seconds == ref.duration_seconds
+    assert ours.data.dtype == ref.data.dtype and ours.data.shape == ref.data.shape
+    assert (ours.data == ref.data).all()
+
+
+def test_load_24bit_and_from_samples(tmp_path, oracle):
+    rng = np.random.default_rng(3)
+    pcm = rng.integers(-2 ** 22, 2 ** 22, size=(24000, 2))
+    path = os.path.join(tmp_path, "b.wav")
+    _write_wav24(path, pcm, 12000, 2)
+    w = DownmixedWavFile(path)
+    assert (w.channels_count, w.framerate, w.sample_width, w.frames_count) == (2, 12000, 3, 24000)
+    w.close()
+    ours = WavStream(path, sample_type="float32")
+    ref = oracle.load_wav_stream(path, sample_type="float32")
+    assert (ours.data == ref.data).all()
+    # from_samples == loading a mono 16-bit file with those samples
+    mono = (rng.standard_normal(30000) * 2000).astype(np.int16)
+    p2 = os.path.join(tmp_path, "c.wav")
+    synth.write_wav(p2, mono, 12000)
+    a = WavStream(p2, sample_type="uint8")
+    b = WavStream.from_samples(mono, 12000, sample_type="uint8")
+    assert (a.data == b.data).all() and a.sample_count == b.sample_count
+
+
+def test_errors(tmp_path):
+    with pytest.raises(SushiError):
+        WavStream("nope.wav", sample_type="int16")
+    with pytest.raises(IOError):                 # as in the reference: open() is outside its try block
+        WavStream(os.path.join(tmp_path, "missing.wav"))
+    eight = os.path.join(tmp_path, "eight.wav")   # 8-bit PCM: fails inside the loader -> wrapped (wav.py:158-159)
+    with open(eight, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<L", 36 + 100) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<LHHLLHH", 16, 1, 1, 8000, 8000, 1, 8))
+        f.write(b"data" + struct.pack("<L", 100) + b"\x80" * 100)
+    with pytest.raises(SushiError) as e:
+        WavStream(eight)
+    assert "Error while loading" in str(e.value) and "Unsupported sample width" in str(e.value)
+    bad = os.path.join(tmp_path, "bad.wav")
+    with open(bad, "wb") as f:
+        f.write(b"RIFX" + b"\0" * 40)
+    with pytest.raises(SushiError) as e:
+        WavStream(bad)
+    assert "RIFF" in str(e.value)
+
+
+def _bare_stream(c):
+    s = WavStream.__new__(WavStream)
+    s.sample_rate, s.sample_count, s.padding_size = c["sample_rate"], c["sample_count"], c["padding_size"]
+    s.data = np.zeros((1, c["data_len"]), c["dtype"])
+    return s
+
+
+def test_window_arithmetic_matches_reference_golden(golden_index):
+    cache = {}
+    for c in golden_index["cases"]:
+        key = (c["sample_rate"], c["framerate"], c["seconds"], c["dtype"])
+        if key not in cache:
+            cache[key] = _bare_stream(c)
+        s = cache[key]
+        pat = s.get_substream(c["pat_start"], c["pat_end"])
+        off = (pat.__array_interface__["data"][0] - s.data.__array_interface__["data"][0]) // pat.itemsize
+        assert (off, pat.shape[1]) == (c["pat_off"], c["pat_len"])
+        start_time, lo, P = s._window(c["pat_len"], c["center"], c["window"])
+        assert lo == c["search_off"]
+        assert P == c["search_len"] - c["pat_len"] + 1
+        if c["ok"]:
+            assert start_time + (c["min_idx"] / float(s.sample_rate)) == c["time"]
+        else:
+            assert P <= 0
+
+
+def test_pattern_provenance():
+    rng = np.random.default_rng(0)
+    a = WavStream.from_samples((rng.standard_normal(40000) * 1000).astype(np.int16), 12000, sample_type="float32")
+    b = WavStream.from_samples((rng.standard_normal(40000) * 1000).astype(np.int16), 12000, sample_type="float32")
+    pat = a.get_substream(0.5, 1.25)
+    st, off, m = _locate(pat)
+    assert st is a and off == a._get_sample_for_time(0.5) and m == pat.shape[1]
+    left, right = np.split(pat, [pat.shape[1] // 2], axis=1)            # sushi.py:445
+    assert _locate(left)[1:] == (off, pat.shape[1] // 2)
+    assert _locate(right)[1:] == (off + pat.shape[1] // 2, pat.shape[1] - pat.shape[1] // 2)
+    assert _locate(b.get_substream(0, 1))[0] is b
+    assert _locate(pat.copy()) is None
+    assert _locate(pat[:, ::2]) is None
+
+
+def test_find_substream_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    rng = np.random.default_rng(0)
+    a = WavStream.from_samples((rng.standard_normal(40000) * 1000).astype(np.int16), 12000, sample_type="float32")
+    with pytest.raises(SushiError):
+        a.find_substream(a.get_substream(0.5, 1.0), 0.5, 1.5)
