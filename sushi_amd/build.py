@@ -25,12 +25,14 @@ def needs_build():
 
 
 def build_native(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -O3 -shared -fPIC csrc/sushi_hip.hip -> lib/libsushi_hip.so"""
+    """hipcc --offload-arch=gfx950 -O3 -shared -fPIC csrc/sushi_hip.hip -> lib/libsushi_hip.so
+    -ffp-contract=off: the float64 epilogue restates cv2's operation order; a fused a*b-c*d would
+    round differently from the reference (the hot loop is MFMA builtins, unaffected)."""
     if not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fvisibility=hidden", "-Wall", SRC, "-o", LIB]
+           "-fvisibility=hidden", "-ffp-contract=off", "-Wall", SRC, "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

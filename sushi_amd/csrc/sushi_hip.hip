@@ -16,8 +16,8 @@
 //     One MFMA tile therefore owns 1024 consecutive positions.  A is read from an LDS copy of
 //     the template chunk laid out with a +1 skew every 32 floats (lane stride 33 -> no bank
 //     conflict), B from a plain contiguous LDS copy of the search tile (lane stride 1).
-//   * f32 accumulation is restarted every KC template samples and folded into float64
-//     accumulators, so the error of the f32 chain stays ~1e-4 absolute on corr.
+//   * f32 accumulation is restarted every FLUSH template samples and folded into float64
+//     accumulators, so the error of the f32 chains stays below cv2's own float32 quantum of corr.
 //   * epilogue: OpenCV common_matchTemplate() in float64, result rounded to float32, packed with
 //     the position into a 64-bit key; wave shuffles + LDS + one atomicMin per workgroup give the
 //     first-index argmin (NumPy argmin semantics).
@@ -34,7 +34,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int KC = 512;          // template samples per f32 accumulation chain / LDS chunk
+constexpr int KC = 512;          // template samples per LDS chunk
+constexpr int FLUSH = 128;       // length of one f32 accumulation chain before it is folded into float64
 constexpr int ROWSPAN = 32 * 31; // 992: largest row shift 32*i of the Toeplitz operand
 constexpr int TLEN = KC + ROWSPAN;              // template samples staged per chunk
 constexpr int TLDS = TLEN + TLEN / 32 + 1;      // with the +1-per-32 skew
@@ -162,24 +163,48 @@ void match_sqdiff_f32_kernel(MatchArgs a) {
         if (wave_active) {
             const float* tp = T_lds + (h + 33 * (31 - i));
             const float* ip = I_lds + (ioff + wb + i + h);
-            for (int nb = 0; nb < KC; nb += 32) {
-                const float* tq = tp + nb + (nb >> 5);
-                const float* iq = ip + nb;
+            for (int nf = 0; nf < KC; nf += FLUSH) {
+                // FLUSH/4 groups of two k-steps (= 4 template samples, 2*NB MFMAs).  The operands of
+                // group g+1 are read from LDS before the MFMAs of group g are issued (register
+                // double buffer); sched_group_barrier pins that order so the matrix pipe never waits
+                // on an LDS round trip.
+                const float* tq = tp + nf + (nf >> 5);
+                const float* iq = ip + nf;
+                float a_cur[2], b_cur[NB][2], a_nxt[2], b_nxt[NB][2];
+                a_cur[0] = tq[0]; a_cur[1] = tq[2];
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const float av = tq[2 * s];
+                for (int b = 0; b < NB; ++b) { b_cur[b][0] = iq[1024 * b]; b_cur[b][1] = iq[1024 * b + 2]; }
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        const float bv = iq[2 * s + 1024 * b];
-                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[b], 0, 0, 0);
+                for (int g = 0; g < FLUSH / 4; ++g) {
+                    if (g + 1 < FLUSH / 4) {
+                        const int n = 4 * (g + 1);                   // offset inside the flush block
+                        const int tn = n + (n >> 5);                 // skewed template offset (nf % 32 == 0)
+                        a_nxt[0] = tq[tn]; a_nxt[1] = tq[tn + 2];
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            b_nxt[b][0] = iq[n + 1024 * b]; b_nxt[b][1] = iq[n + 1024 * b + 2];
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x100, NB + 1, 0);   // DS reads of group g+1
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                        for (int b = 0; b < NB; ++b)
+                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[k], b_cur[b][k], acc[b], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x8, 2 * NB, 0);         // MFMAs of group g
+                    if (g + 1 < FLUSH / 4) {
+                        a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1];
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) { b_cur[b][0] = b_nxt[b][0]; b_cur[b][1] = b_nxt[b][1]; }
                     }
                 }
-            }
-            // fold the f32 chain into the float64 accumulators
+                // fold the f32 chain (FLUSH products long) into the float64 accumulators
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
+                for (int b = 0; b < NB; ++b) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { acc2[b][r] += (double)acc[b][r]; acc[b][r] = 0.f; }
+                    for (int r = 0; r < 16; ++r) { acc2[b][r] += (double)acc[b][r]; acc[b][r] = 0.f; }
+                }
             }
         }
     }
