@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- events/s of the batched template match on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path (sushi_hip_match_batch: memset + match kernel + unpack, and
-for N > 1 the all-gather of (index, score)) over one batch of synthetic searches whose streams and
-descriptors are already resident in HBM.  Workload at every N: BASELINE.json configs[1] per GPU
+A "step" is one pass of the hot path over one batch of synthetic searches whose streams (and, for
+the FFT path, the destination stream's block spectra -- built once per stream, like the prefix
+sums) and descriptors are already resident in HBM: sushi_hip_match_batch_fft (template DFTs,
+frequency-domain multiply-accumulate, inverse DFTs + scoring, exact refinement, unpack; default)
+or sushi_hip_match_batch (--path direct: the exact-f32 MFMA kernel), and for N > 1 the all-gather
+of (index, score).  Workload at every N: BASELINE.json configs[1] per GPU
 (1000 events, 45-min 12 kHz float32 src/dst, +-60 s window => P = 1,440,001 positions, templates
 U[1,5] s) -- weak scaling, streams replicated, events sharded in contiguous blocks.
 
@@ -99,6 +102,9 @@ def main():
     ap.add_argument("--offset", type=float, default=7.25, help="planted src->dst offset in seconds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=None)
+    ap.add_argument("--path", choices=("fft", "direct"), default="fft")
+    ap.add_argument("--ws-mb", type=int, default=None, help="FFT path scratch per batch (MiB)")
+    ap.add_argument("--delta", type=float, default=None)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -151,8 +157,13 @@ def main():
     dst._device = src._device = dev
     ddev, sdev = dst.device_stream(), src.device_stream()
 
+    from sushi_amd import _native
+    from sushi_amd.device import DEFAULT_DELTA
+
     def make_batch(lo, hi):
-        return SearchBatch(ddev, sdev, offs[lo:hi], lens[lo:hi], wst[lo:hi], npos[lo:hi], variant=args.variant)
+        return SearchBatch(ddev, sdev, offs[lo:hi], lens[lo:hi], wst[lo:hi], npos[lo:hi], variant=args.variant,
+                           path=args.path, delta=DEFAULT_DELTA if args.delta is None else args.delta,
+                           workspace_bytes=None if args.ws_mb is None else args.ws_mb << 20)
 
     sharded = ShardedSearch(n_total, make_batch)
     batch = sharded.batch
@@ -179,11 +190,14 @@ def main():
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     sync()
+    if args.path == "fft":
+        _native.profile_begin()           # per-stage HIP events on the launch stream, read after the final sync
     t0 = time.perf_counter()
     for k in range(args.steps):
         idx_all, score_all = step(starts[k], ends[k])
     sync()
     elapsed = time.perf_counter() - t0
+    stage_ms = _native.profile_end(args.steps).mean(axis=0) if args.path == "fft" else None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -209,8 +223,35 @@ def main():
             max_idx_err_vs_oracle, max_rel_score_err, max_abs_score_err = int(max(ie)), float(max(se)), float(max(ae))
         value = n_total * args.steps / elapsed
         flops_launch = batch.flops
-        achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
-        hbm_achieved = batch.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
+        if args.path == "fft":
+            # dominant kernel of the step = the stage with the largest HIP-event time; its duration is
+            # the sum over the step's sub-batch launches of that kernel
+            stages = {n: float(v) for n, v in zip(_native.STAGE_NAMES, stage_ms)}
+            dom = max(stages, key=stages.get)
+            dom_ms = stages[dom]
+            kname = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "ifft_kernel",
+                     "refine": "refine_kernel", "finish": "match_flagged_kernel+unpack_keys_kernel"}[dom]
+            achieved = batch.algorithmic_bytes / (dom_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": achieved / PEAK_HBM_GBPS, "traffic": None,
+                        "kernel": kname, "kernel_ms": dom_ms, "stage_ms": stages,
+                        "step_kernels_ms": kernel_ms,
+                        "step_hbm_achieved_GBps": batch.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9,
+                        "algorithmic_bytes_per_launch": batch.algorithmic_bytes,
+                        "direct_form_flop_per_launch": flops_launch,
+                        "direct_form_equivalent_TFLOPs": flops_launch / (kernel_ms * 1e-3) / 1e12,
+                        "fft_pairs": batch.fft_pairs, "fft_segments": batch.fft_segs,
+                        "workspace_bytes": batch.ws_bytes, "delta": batch.delta,
+                        "searches_finished_by_direct_kernel": batch.fallback_count()}
+        else:
+            achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
+            hbm_achieved = batch.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
+            roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                        "kernel": "match_sqdiff_f32_kernel", "kernel_ms": kernel_ms,
+                        "algorithmic_flop_per_launch": flops_launch,
+                        "algorithmic_bytes_per_launch": batch.algorithmic_bytes,
+                        "hbm_achieved_GBps": hbm_achieved, "hbm_frac": hbm_achieved / PEAK_HBM_GBPS}
         out = {
             "metric": METRIC, "value": value, "unit": "events/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -223,15 +264,12 @@ def main():
                        "events_per_gpu": args.events, "global_events": n_total, "window_s": args.window,
                        "stream_minutes": args.minutes, "sample_rate": args.rate, "sample_type": args.sample_type,
                        "method": "TM_SQDIFF_NORMED+argmin (what wav.py:185-186 does; see SURVEY F1)",
+                       "path": ("overlap-save FFT (f32) + exact float64 re-evaluation of the near-minimum positions"
+                                if args.path == "fft" else "direct exact-f32 MFMA sliding dot product"),
                        "parallelism": "events sharded in contiguous blocks over %d GPU(s), streams replicated, "
                                       "one all-gather of (idx, score)" % world,
                        "kernel_variant": batch.variant},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "match_sqdiff_f32_kernel", "kernel_ms": kernel_ms,
-                         "algorithmic_flop_per_launch": flops_launch,
-                         "algorithmic_bytes_per_launch": batch.algorithmic_bytes,
-                         "hbm_achieved_GBps": hbm_achieved, "hbm_frac": hbm_achieved / PEAK_HBM_GBPS},
+            "roofline": roofline,
             "cpu_baseline": cpu,
             "parity": {"max_shift_err_samples_vs_planted": max_shift_err_vs_planted,
                        "max_idx_err_vs_oracle_sample": max_idx_err_vs_oracle,

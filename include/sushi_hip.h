@@ -12,6 +12,13 @@
  *                              (wav.py:108-162 builds `self.data`; this runs right after).
  *   sushi_hip_match_batch      replaces wav.py:185-186 for a whole batch of
  *                              (pattern, window) pairs; one launch, one (index, score) per pair.
+ *                              Direct form: exact-f32 MFMA sliding dot product, O(P*M).
+ *   sushi_hip_prepare_spectra  block DFTs of the search stream, once per WavStream (cv2's crossCorr
+ *                              recomputes them inside every matchTemplate call).
+ *   sushi_hip_match_batch_fft  the same contract as sushi_hip_match_batch through overlap-save FFT
+ *                              (what cv2's crossCorr does): f32 FFT scores for every position, then
+ *                              the exact float64 evaluation of every position within `delta` of the
+ *                              minimum; searches with too many near-ties are finished by the direct kernel.
  *
  * Conventions: extern "C", plain pointers and sizes, no C++ or torch types.  Every pointer
  * named *_dev is a device (HBM) pointer owned by the caller for the duration of the call's
@@ -29,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SUSHI_HIP_ABI_VERSION 1
+#define SUSHI_HIP_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define SUSHI_HIP_API __attribute__((visibility("default")))
@@ -61,9 +68,11 @@ typedef struct SushiHipSearch {
     int64_t win_start;
     int32_t tmpl_len;
     int32_t n_pos;
-    int32_t first_tile;
+    int32_t first_tile;   /* direct path: tiles of the searches before this one */
+    int32_t first_pair;   /* FFT path: block pairs of the searches before this one (sushi_hip_fft_layout) */
+    int32_t first_seg;    /* FFT path: template segments of the searches before this one */
     int32_t reserved;
-} SushiHipSearch;
+} SushiHipSearch;         /* 40 bytes */
 
 SUSHI_HIP_API int sushi_hip_abi_version(void);
 SUSHI_HIP_API const char* sushi_hip_strerror(int code);
@@ -101,6 +110,58 @@ SUSHI_HIP_API int sushi_hip_match_batch(const float* dst_xc_dev, const double* d
                           const SushiHipSearch* searches_dev, int n_search, int n_tiles, int variant,
                           uint64_t* keys_ws_dev, int32_t* out_idx_dev, float* out_score_dev,
                           void* hip_stream);
+
+/* ---- overlap-save FFT path ------------------------------------------------------------------
+ * The destination stream is cut into blocks of sushi_hip_fft_hop() = B samples; block j is
+ * stored as the 2B-point complex DFT of xc[jB .. jB+2B) + i * xc[(j+1)B .. (j+3)B) (zeros past
+ * the end), 2B complex float32 each: sushi_hip_spectra_bytes(n) = ceil(n/B) * 2B * 8 bytes.
+ * A search covers the blocks floor(win_start/B) .. floor((win_start+n_pos-1)/B), two per
+ * "pair", and its template is cut into ceil(tmpl_len/B) segments. */
+SUSHI_HIP_API int sushi_hip_fft_hop(void);
+SUSHI_HIP_API int64_t sushi_hip_spectra_blocks(int64_t n);
+SUSHI_HIP_API size_t sushi_hip_spectra_bytes(int64_t n);
+SUSHI_HIP_API int sushi_hip_fft_layout(int64_t win_start, int32_t n_pos, int32_t tmpl_len,
+                                       int32_t* n_pairs, int32_t* n_seg);
+/* Workspace needed to run one search of that shape (the call splits a batch into sub-batches
+ * that fit the workspace it is given; more workspace = fewer, larger launches). */
+SUSHI_HIP_API size_t sushi_hip_fft_workspace_bytes(int32_t n_pairs, int32_t n_seg);
+
+/* xc_dev: centred stream from sushi_hip_prepare_stream (16-byte aligned); spec_dev: output. */
+SUSHI_HIP_API int sushi_hip_prepare_spectra(const float* xc_dev, int64_t n, void* spec_dev, size_t spec_bytes,
+                                            void* hip_stream);
+
+/* Same results as sushi_hip_match_batch.  Additional arguments:
+ *   dst_spec_dev      : sushi_hip_prepare_spectra output for the dst stream
+ *   searches_host     : the same n_search descriptors in host memory (read during the call only);
+ *                       first_tile must be laid out for variant sushi_hip_variant_count()-1,
+ *                       first_pair / first_seg as running sums of sushi_hip_fft_layout()
+ *   delta             : score margin (> 2x the FFT error; 2e-5 is ample for WavStream data)
+ *   ws_dev / ws_bytes : scratch, >= sushi_hip_fft_workspace_bytes of the largest search
+ *   keys_ws_dev       : uint64[2 * n_search] scratch
+ *   flags_dev         : int32[2 * n_search + 2] scratch; on completion flags[k] = 1 if search k had too
+ *                       many near-ties and was finished by the direct kernel, flags[n_search] = how many */
+SUSHI_HIP_API int sushi_hip_match_batch_fft(const float* dst_xc_dev, const double* dst_s1_dev, const double* dst_s2_dev, int64_t dst_len,
+                              const void* dst_spec_dev,
+                              const float* src_xc_dev, const double* src_s1_dev, const double* src_s2_dev, int64_t src_len,
+                              double centre, int method,
+                              const SushiHipSearch* searches_dev, const SushiHipSearch* searches_host,
+                              int n_search, double delta,
+                              void* ws_dev, size_t ws_bytes,
+                              uint64_t* keys_ws_dev, int32_t* flags_dev,
+                              int32_t* out_idx_dev, float* out_score_dev, void* hip_stream);
+
+/* Optional per-stage timing of sushi_hip_match_batch_fft with HIP events recorded on the launch
+ * stream (bench.py's roofline figures).  Between _begin and _end every call records its stage
+ * boundaries; _end waits for them and writes, per call, the milliseconds spent in each stage
+ * (summed over the call's sub-batches) into stage_ms[call][SUSHI_HIP_NSTAGES].  Not thread safe. */
+#define SUSHI_HIP_NSTAGES 5
+#define SUSHI_HIP_STAGE_TSPEC 0    /* template-segment DFTs                          */
+#define SUSHI_HIP_STAGE_MAC 1      /* frequency-domain multiply-accumulate           */
+#define SUSHI_HIP_STAGE_IFFT 2     /* inverse DFTs + scoring epilogue                */
+#define SUSHI_HIP_STAGE_REFINE 3   /* exact float64 evaluation of the candidates     */
+#define SUSHI_HIP_STAGE_FINISH 4   /* direct-kernel fallback (if any) + unpack       */
+SUSHI_HIP_API int sushi_hip_profile_begin(void);
+SUSHI_HIP_API int sushi_hip_profile_end(float* stage_ms, int max_calls, int* n_calls);
 
 #ifdef __cplusplus
 }

@@ -18,10 +18,15 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sushi_hip.h")
 U8, F32 = 0, 1
 SQDIFF_NORMED = 0
 
-# struct SushiHipSearch, 32 bytes
+ABI_VERSION = 2
+NSTAGES = 5
+STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish")
+
+# struct SushiHipSearch, 40 bytes
 SEARCH_DTYPE = np.dtype([("tmpl_off", "<i8"), ("win_start", "<i8"), ("tmpl_len", "<i4"),
-                         ("n_pos", "<i4"), ("first_tile", "<i4"), ("reserved", "<i4")], align=True)
-assert SEARCH_DTYPE.itemsize == 32
+                         ("n_pos", "<i4"), ("first_tile", "<i4"), ("first_pair", "<i4"),
+                         ("first_seg", "<i4"), ("reserved", "<i4")], align=True)
+assert SEARCH_DTYPE.itemsize == 40
 
 _lib = None
 
@@ -62,7 +67,25 @@ def lib():
     L.sushi_hip_prepare_stream.argtypes = [vp, ci, i64, vp, vp, vp, vp, sz, vp]
     L.sushi_hip_match_batch.restype = ci
     L.sushi_hip_match_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp, i64, dbl, ci, vp, ci, ci, ci, vp, vp, vp, vp]
-    if L.sushi_hip_abi_version() != 1:
+    i32 = ctypes.c_int32
+    L.sushi_hip_fft_hop.restype = ci
+    L.sushi_hip_spectra_blocks.restype = i64
+    L.sushi_hip_spectra_blocks.argtypes = [i64]
+    L.sushi_hip_spectra_bytes.restype = sz
+    L.sushi_hip_spectra_bytes.argtypes = [i64]
+    L.sushi_hip_fft_layout.restype = ci
+    L.sushi_hip_fft_layout.argtypes = [i64, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.sushi_hip_fft_workspace_bytes.restype = sz
+    L.sushi_hip_fft_workspace_bytes.argtypes = [i32, i32]
+    L.sushi_hip_prepare_spectra.restype = ci
+    L.sushi_hip_prepare_spectra.argtypes = [vp, i64, vp, sz, vp]
+    L.sushi_hip_match_batch_fft.restype = ci
+    L.sushi_hip_match_batch_fft.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, i64, dbl, ci, vp, vp, ci, dbl,
+                                            vp, sz, vp, vp, vp, vp, vp]
+    L.sushi_hip_profile_begin.restype = ci
+    L.sushi_hip_profile_end.restype = ci
+    L.sushi_hip_profile_end.argtypes = [vp, ci, ctypes.POINTER(ci)]
+    if L.sushi_hip_abi_version() != ABI_VERSION:
         raise NativeError("libsushi_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -77,3 +100,27 @@ def check(rc, what):
 def variant_tiles():
     L = lib()
     return [L.sushi_hip_variant_tile_positions(v) for v in range(L.sushi_hip_variant_count())]
+
+
+def fft_layout(win_start, n_pos, tmpl_len):
+    """Vectorised twin of sushi_hip_fft_layout (csrc/sushi_common.hpp fft_layout): block pairs and
+    template segments per search.  sushi_hip_match_batch_fft re-derives and checks the running sums."""
+    hop = lib().sushi_hip_fft_hop()
+    w = np.asarray(win_start, dtype=np.int64)
+    p = np.asarray(n_pos, dtype=np.int64)
+    m = np.asarray(tmpl_len, dtype=np.int64)
+    k0 = w // hop
+    kl = (w + p - 1) // hop
+    return (kl - k0 + 2) // 2, (m + hop - 1) // hop
+
+
+def profile_begin():
+    check(lib().sushi_hip_profile_begin(), "sushi_hip_profile_begin")
+
+
+def profile_end(max_calls):
+    """-> float32[n_calls, NSTAGES] milliseconds per stage of every FFT-path call since profile_begin."""
+    buf = np.zeros((max(1, max_calls), NSTAGES), np.float32)
+    n = ctypes.c_int(0)
+    check(lib().sushi_hip_profile_end(buf.ctypes.data, int(max_calls), ctypes.byref(n)), "sushi_hip_profile_end")
+    return buf[:n.value]

@@ -1,13 +1,29 @@
-"""Build libsushi_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libsushi_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+Two translation units, compiled separately (the MFMA kernel alone takes ~2 min) and linked:
+  csrc/sushi_hip.hip  direct MFMA kernel, stream preparation, exact refinement   (-ffp-contract=off)
+  csrc/sushi_fft.hip  overlap-save FFT path
+"""
+import math
 import os
 import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(_HERE, "csrc", "sushi_hip.hip")
+CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "sushi_hip.h")
 LIB_DIR = os.path.join(_HERE, "lib")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB = os.path.join(LIB_DIR, "libsushi_hip.so")
+TWIDDLE_INC = os.path.join(CSRC, "_gen_twiddle8192.inc")
+
+COMMON_DEPS = [HEADER, os.path.join(CSRC, "sushi_common.hpp"), os.path.join(CSRC, "sushi_internal.hpp")]
+# -ffp-contract=off for sushi_hip.hip: its float64 epilogue restates cv2's operation order; a fused
+# a*b-c*d would round differently from the reference (the hot loop is MFMA builtins, unaffected).
+UNITS = [
+    ("sushi_hip", ["-ffp-contract=off"], []),
+    ("sushi_fft", [], [os.path.join(CSRC, "fft_core.hpp"), os.path.join(CSRC, "mac_core.hpp"), TWIDDLE_INC]),
+]
 
 
 def _hipcc():
@@ -17,24 +33,61 @@ def _hipcc():
     raise RuntimeError("hipcc not found (need ROCm to build libsushi_hip.so)")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def write_twiddles(n=8192):
+    """exp(-2*pi*i*k/n) as float32 literals (interleaved re, im), correctly rounded from float64."""
+    import numpy as np
+    k = np.arange(n, dtype=np.float64)
+    ang = 2.0 * math.pi * k / n
+    tab = np.empty(2 * n, np.float32)
+    tab[0::2] = np.cos(ang)
+    tab[1::2] = -np.sin(ang)
+    text = "".join("%.9ef,%s" % (float(v), "\n" if i % 8 == 7 else " ") for i, v in enumerate(tab))
+    if not os.path.exists(TWIDDLE_INC) or open(TWIDDLE_INC).read() != text:
+        with open(TWIDDLE_INC, "w") as f:
+            f.write(text)
+    return TWIDDLE_INC
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    m = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > m for p in (SRC, HEADER))
+    m = os.path.getmtime(target)
+    return any(os.path.getmtime(p) > m for p in deps)
+
+
+def needs_build():
+    if not os.path.exists(TWIDDLE_INC):
+        return True
+    deps = list(COMMON_DEPS)
+    for name, _flags, extra in UNITS:
+        deps += [os.path.join(CSRC, name + ".hip")] + extra
+    return _stale(LIB, deps)
 
 
 def build_native(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -O3 -shared -fPIC csrc/sushi_hip.hip -> lib/libsushi_hip.so
-    -ffp-contract=off: the float64 epilogue restates cv2's operation order; a fused a*b-c*d would
-    round differently from the reference (the hot loop is MFMA builtins, unaffected)."""
+    """hipcc --offload-arch=gfx950 -O3 -c csrc/*.hip -> lib/obj/*.o -> lib/libsushi_hip.so"""
+    write_twiddles()
     if not force and not needs_build():
         return LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fvisibility=hidden", "-ffp-contract=off", "-Wall", SRC, "-o", LIB]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall"]
+    objs, procs = [], []
+    for name, flags, extra in UNITS:
+        src = os.path.join(CSRC, name + ".hip")
+        obj = os.path.join(OBJ_DIR, name + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + COMMON_DEPS + extra):
+            cmd = base + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-o", LIB]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB
 

@@ -1,0 +1,165 @@
+// sushi_amd/csrc/fft_core.hpp -- workgroup FFT (complex f32, N = 8192, 512 threads x 16 points) for gfx950.
+//
+// Used by the overlap-save form of the template match (DESIGN.md "FFT path"): forward transforms of
+// destination-stream blocks and template segments, inverse transforms of the per-block products.
+// OpenCV's crossCorr() (templmatch.cpp, behind cv2.matchTemplate at reference wav.py:185) is the same
+// block-DFT scheme on the CPU.
+//
+// Stockham autosort, radix plan 16 x 8 x 8 x 8.  A pass of radix R with NS = product of the earlier
+// radices processes butterflies j = 0 .. N/R-1:
+//     inputs   x[j + t*N/R] * w^(t*k),   k = j mod NS,  w = exp(DIR*2*pi*i / (NS*R)),  t = 0..R-1
+//     outputs  y[(j - k)*R + k + t*NS]   = R-point DFT of the inputs
+// Pass 1 has NS = 1 (no twiddles) and takes its inputs from registers (the caller loads them from
+// HBM); the last pass leaves its outputs in registers: thread `tid` ends with X[tid + 512*m], m = 0..15.
+// Between passes the data goes through one LDS buffer, padded by one element per 16 so that the
+// transposing stores of every pass are bank-conflict free (ds_write_b64: 16-lane groups, 32 banks).
+//
+// Everything here is written against explicit (tid, lds) arguments so that tests/host_fft_check.cpp
+// can run the same code on the CPU, one "thread" at a time, with the barriers replaced by loops.
+#ifndef SUSHI_FFT_CORE_HPP
+#define SUSHI_FFT_CORE_HPP
+
+#ifdef __HIPCC__
+#define SUSHI_HD __device__ __forceinline__
+#else
+#define SUSHI_HD inline
+#endif
+
+namespace sushi_fft {
+
+constexpr int N = 8192;          // transform length (complex points)
+constexpr int NT = 512;          // threads per workgroup
+constexpr int PER = N / NT;      // 16 points per thread
+constexpr int LDS_ELEMS = N + N / 16;   // padded buffer, in complex elements
+
+struct cpx { float x, y; };
+
+SUSHI_HD cpx cadd(cpx a, cpx b) { return cpx{a.x + b.x, a.y + b.y}; }
+SUSHI_HD cpx csub(cpx a, cpx b) { return cpx{a.x - b.x, a.y - b.y}; }
+SUSHI_HD cpx cmul(cpx a, cpx b) { return cpx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+SUSHI_HD cpx cconj(cpx a) { return cpx{a.x, -a.y}; }
+SUSHI_HD int pad(int e) { return e + (e >> 4); }
+
+// exp(DIR * 2*pi*i * q/16), q = 0..7, as compile-time cases (q is a constant after unrolling)
+template <int DIR>
+SUSHI_HD cpx mul_root16(cpx a, int q) {
+    const float C1 = 0.92387953251128673848f, S1 = 0.38268343236508978178f, H = 0.70710678118654752440f;
+    const float s = (float)DIR;
+    switch (q) {
+        case 0: return a;
+        case 1: return cmul(a, cpx{C1, s * S1});
+        case 2: return cpx{H * (a.x - s * a.y), H * (a.y + s * a.x)};
+        case 3: return cmul(a, cpx{S1, s * C1});
+        case 4: return cpx{-s * a.y, s * a.x};
+        case 5: return cmul(a, cpx{-S1, s * C1});
+        case 6: return cpx{-H * (a.x + s * a.y), H * (s * a.x - a.y)};
+        default: return cmul(a, cpx{-C1, s * S1});
+    }
+}
+
+// in-place R-point DFT, natural order in and out: v[t] <- sum_u v[u] * exp(DIR*2*pi*i*t*u/R)
+template <int R, int DIR>
+struct Dft {
+    static SUSHI_HD void run(cpx* v) {
+        cpx e[R / 2], o[R / 2];
+#pragma unroll
+        for (int u = 0; u < R / 2; ++u) { e[u] = v[2 * u]; o[u] = v[2 * u + 1]; }
+        Dft<R / 2, DIR>::run(e);
+        Dft<R / 2, DIR>::run(o);
+#pragma unroll
+        for (int t = 0; t < R / 2; ++t) {
+            const cpx ow = mul_root16<DIR>(o[t], t * (16 / R));
+            v[t] = cadd(e[t], ow);
+            v[t + R / 2] = csub(e[t], ow);
+        }
+    }
+};
+template <int DIR>
+struct Dft<1, DIR> {
+    static SUSHI_HD void run(cpx*) {}
+};
+
+// One pass, register side: twiddle (unless NS == 1) and butterfly the PER points of this thread.
+// v[b*R + t] holds input t of butterfly j = tid + b*NT.
+// tw[n] = exp(-2*pi*i*n/N), n = 0..N-1 (the forward table; the inverse conjugates it).
+template <int R, int NS, int DIR>
+SUSHI_HD void pass_compute(cpx* v, int tid, const cpx* __restrict__ tw) {
+    constexpr int NB = PER / R;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        cpx* x = v + b * R;
+        if (NS > 1) {
+            const int j = tid + b * NT;
+            const int k = j & (NS - 1);
+            cpx w1 = tw[k * (N / (NS * R))];
+            if (DIR > 0) w1 = cconj(w1);
+            cpx w[R];
+            w[1] = w1;
+#pragma unroll
+            for (int t = 2; t < R; ++t) w[t] = (t & 1) ? cmul(w[t - 1], w1) : cmul(w[t / 2], w[t / 2]);
+#pragma unroll
+            for (int t = 1; t < R; ++t) x[t] = cmul(x[t], w[t]);
+        }
+        Dft<R, DIR>::run(x);
+    }
+}
+
+// store the outputs of a pass into the (padded) LDS buffer
+template <int R, int NS>
+SUSHI_HD void pass_store(const cpx* v, int tid, cpx* lds) {
+    constexpr int NB = PER / R;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = tid + b * NT;
+        const int k = j & (NS - 1);
+        const int base = (j - k) * R + k;
+#pragma unroll
+        for (int t = 0; t < R; ++t) lds[pad(base + t * NS)] = v[b * R + t];
+    }
+}
+
+// load the inputs of a radix-R pass from the LDS buffer
+template <int R>
+SUSHI_HD void pass_load(cpx* v, int tid, const cpx* lds) {
+    constexpr int NB = PER / R;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = tid + b * NT;
+#pragma unroll
+        for (int t = 0; t < R; ++t) v[b * R + t] = lds[pad(j + t * (N / R))];
+    }
+}
+
+// Index maps of the whole transform (what the caller needs to load / interpret registers):
+//   input : v[t]        = x[tid + 512*t]                  t = 0..15   (pass 1 is radix 16, one butterfly per thread)
+//   output: v[b*8 + t]  = X[tid + 512*(b + 2*t)]          b = 0..1, t = 0..7
+SUSHI_HD int in_index(int tid, int r) { return tid + NT * r; }
+SUSHI_HD int out_index(int tid, int r) { return tid + NT * ((r >> 3) + 2 * (r & 7)); }
+
+#ifdef __HIPCC__
+#define SUSHI_FFT_BARRIER() __syncthreads()
+// Full transform of the 16 points in v (in_index layout) -> v (out_index layout).
+// `lds` must hold LDS_ELEMS elements; contents are dead after the call's last barrier... the buffer may be
+// reused by the caller after one further __syncthreads().
+template <int DIR>
+__device__ __forceinline__ void fft8192(cpx* v, int tid, cpx* lds, const cpx* __restrict__ tw) {
+    pass_compute<16, 1, DIR>(v, tid, tw);
+    pass_store<16, 1>(v, tid, lds);
+    SUSHI_FFT_BARRIER();
+    pass_load<8>(v, tid, lds);
+    pass_compute<8, 16, DIR>(v, tid, tw);
+    SUSHI_FFT_BARRIER();
+    pass_store<8, 16>(v, tid, lds);
+    SUSHI_FFT_BARRIER();
+    pass_load<8>(v, tid, lds);
+    pass_compute<8, 128, DIR>(v, tid, tw);
+    SUSHI_FFT_BARRIER();
+    pass_store<8, 128>(v, tid, lds);
+    SUSHI_FFT_BARRIER();
+    pass_load<8>(v, tid, lds);
+    pass_compute<8, 1024, DIR>(v, tid, tw);
+}
+#endif
+
+}  // namespace sushi_fft
+#endif

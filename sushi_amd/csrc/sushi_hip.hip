@@ -29,8 +29,12 @@
 #include <float.h>
 
 #include "../../include/sushi_hip.h"
+#include "sushi_common.hpp"
+#include "sushi_internal.hpp"
 
 namespace {
+
+using namespace sushi;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -56,46 +60,20 @@ struct MatchArgs {
     unsigned long long* keys;
 };
 
-// XCD-aware remap (MI355X: block b runs on XCD b % 8): give every XCD a contiguous run of
-// logical tiles so that the tiles of one search (same template, overlapping windows) share an L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7;
-    const int xcd = bid & 7, k = bid >> 3;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + k;
-}
+template <int WAVES, int NB> struct TileShape {
+    static constexpr int NT = WAVES * 64;
+    static constexpr int TP = WAVES * NB * 1024;        // positions per workgroup
+    static constexpr int ILEN = TP + KC - 984;          // search samples staged per chunk: TP-1024+32 columns + KC rows + align slack, multiple of 4
+    static constexpr int LDS_FLOATS = ILEN + TLDS;
+};
 
-__device__ __forceinline__ unsigned long long shfl_down_u64(unsigned long long v, int d) {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    lo = __shfl_down(lo, d, 64);
-    hi = __shfl_down(hi, d, 64);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-// OpenCV templmatch.cpp common_matchTemplate(), TM_SQDIFF_NORMED branch, one position.
-// corr_u: sum T*I (uncentred), wU: sum I^2 over the window, tU: sum T^2, tnorm: sqrt(tU).
-__device__ __forceinline__ float finish_sqdiff_normed(double corr_u, double wU, double tU, double tnorm) {
-    double num = (double)(float)corr_u;          // cv2 keeps corr in its float32 result Mat
-    num = wU - 2.0 * num + tU;
-    num = num > 0.0 ? num : 0.0;
-    const double diff2 = wU > 0.0 ? wU : 0.0;
-    double lim = 10.0 * (double)FLT_EPSILON * wU;
-    lim = lim < 0.5 ? lim : 0.5;
-    const double t = (diff2 <= lim) ? 0.0 : sqrt(diff2) * tnorm;
-    double r;
-    if (num < t) r = num / t;
-    else r = 1.0;                                // both other branches give 1 for SQDIFF_NORMED (num >= 0)
-    return (float)r;
-}
-
+// One tile (TP consecutive result positions) of one search.  `lds` holds LDS_FLOATS floats, `red` WAVES keys.
 template <int WAVES, int NB>
-__global__ __launch_bounds__(WAVES * 64, 2)
-void match_sqdiff_f32_kernel(MatchArgs a) {
-    constexpr int NT = WAVES * 64;
-    constexpr int TP = WAVES * NB * 1024;        // positions per workgroup
-    constexpr int ILEN = TP + KC - 984;          // search samples staged per chunk: TP-1024+32 columns + KC rows + align slack, multiple of 4
-    __shared__ __attribute__((aligned(16))) float lds[ILEN + TLDS];
-    __shared__ unsigned long long red[WAVES];
+__device__ __forceinline__ void match_tile(const MatchArgs& a, const int s_idx, const SushiHipSearch sd,
+                                           const int tile_in_search, float* lds, unsigned long long* red) {
+    constexpr int NT = TileShape<WAVES, NB>::NT;
+    constexpr int TP = TileShape<WAVES, NB>::TP;
+    constexpr int ILEN = TileShape<WAVES, NB>::ILEN;
     float* I_lds = lds;
     float* T_lds = lds + ILEN;
 
@@ -105,18 +83,9 @@ void match_sqdiff_f32_kernel(MatchArgs a) {
     const int i = lane & 31;                     // MFMA row (A) / column (B) index of this lane
     const int h = lane >> 5;                     // MFMA k index of this lane
 
-    // ---- which search / which tile ------------------------------------------------------
-    const int tile = xcd_remap(blockIdx.x, a.n_tiles);
-    int lo = 0, hi = a.n_search - 1;             // last search with first_tile <= tile
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (a.searches[mid].first_tile <= tile) lo = mid; else hi = mid - 1;
-    }
-    const SushiHipSearch sd = a.searches[lo];
-    const int s_idx = lo;
     const int M = sd.tmpl_len;
     const int P = sd.n_pos;
-    const int p0 = (tile - sd.first_tile) * TP;  // first position of this workgroup
+    const int p0 = tile_in_search * TP;          // first position of this workgroup
     const int wb = wave * (NB * 1024);           // first position of this wave inside the tile
     const bool wave_active = (p0 + wb) < P;
 
@@ -212,20 +181,7 @@ void match_sqdiff_f32_kernel(MatchArgs a) {
     // ---- epilogue: normalise, pack (score, position), arg-min ------------------------------
     unsigned long long best = ~0ull;
     if (wave_active) {
-        const double cM = a.centre * a.centre * (double)M;
-        const double tS1 = a.src_s1[sd.tmpl_off + M] - a.src_s1[sd.tmpl_off];
-        const double tS2 = a.src_s2[sd.tmpl_off + M] - a.src_s2[sd.tmpl_off];
-        // template statistics in the order cv2 derives them (meanStdDev -> templSum2 / templNorm)
-        const double t_sum = tS1 + a.centre * (double)M;          // sum T   (uncentred)
-        const double t_sq = tS2 + 2.0 * a.centre * tS1 + cM;      // sum T^2 (uncentred)
-        const double invArea = 1.0 / (double)M;
-        const double t_mean = t_sum * invArea;
-        double t_var = t_sq * invArea - t_mean * t_mean;
-        t_var = t_var > 0.0 ? t_var : 0.0;
-        const double t_sdv = sqrt(t_var);
-        const double t_norm2 = t_sdv * t_sdv + t_mean * t_mean;   // templSum2 before "/= invArea"
-        const double tU = t_norm2 / invArea;                      // templSum2
-        const double tnorm = sqrt(t_norm2) / sqrt(invArea);       // templNorm
+        const TemplStats ts = templ_stats(a.src_s1, a.src_s2, sd.tmpl_off, M, a.centre);
         const double* __restrict__ w1 = a.dst_s1 + sd.win_start;
         const double* __restrict__ w2 = a.dst_s2 + sd.win_start;
 #pragma unroll
@@ -236,30 +192,64 @@ void match_sqdiff_f32_kernel(MatchArgs a) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int p = p0 + wb + 1024 * b + 32 * row + i;
                 if (p < P) {
-                    const double wS1 = w1[p + M] - w1[p];
-                    const double wS2 = w2[p + M] - w2[p];
-                    const double wU = wS2 + 2.0 * a.centre * wS1 + cM;               // sum I^2 over the window
-                    const double corr_u = acc2[b][r] + a.centre * (tS1 + wS1) + cM;  // sum T*I
-                    const float score = finish_sqdiff_normed(corr_u, wU, tU, tnorm);
-                    const unsigned long long key =
-                        ((unsigned long long)__float_as_uint(score) << 32) | (unsigned)p;
+                    const float score = score_at(acc2[b][r], ts, a.centre, w1, w2, p, M);
+                    const unsigned long long key = make_key(score, (unsigned)p);
                     best = key < best ? key : best;
                 }
             }
         }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long o = shfl_down_u64(best, d);
-        best = o < best ? o : best;
-    }
+    best = wave_min_u64(best);
     if (lane == 0) red[wave] = best;
     __syncthreads();
     if (tid == 0) {
         unsigned long long m = red[0];
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) m = red[w] < m ? red[w] : m;
-        if (m != ~0ull) atomicMin(a.keys + s_idx, m);
+        if (m != NO_KEY) atomicMin(a.keys + s_idx, m);
+    }
+}
+
+
+template <int WAVES, int NB>
+__global__ __launch_bounds__(WAVES * 64, 2)
+void match_sqdiff_f32_kernel(MatchArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[TileShape<WAVES, NB>::LDS_FLOATS];
+    __shared__ unsigned long long red[WAVES];
+    // ---- which search / which tile ------------------------------------------------------
+    const int tile = xcd_remap(blockIdx.x, a.n_tiles);
+    int lo = 0, hi = a.n_search - 1;             // last search with first_tile <= tile
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.searches[mid].first_tile <= tile) lo = mid; else hi = mid - 1;
+    }
+    const SushiHipSearch sd = a.searches[lo];
+    match_tile<WAVES, NB>(a, lo, sd, tile - sd.first_tile, lds, red);
+}
+
+// Fallback of the FFT path: the same tiles, only for the searches the refinement flagged
+// (flags[n_search] = how many, flags[n_search + 2 ..] = which).  Fixed grid, workgroups stride over
+// the (flagged search, tile) work items; with nothing flagged every workgroup leaves after one load.
+template <int WAVES, int NB>
+__global__ __launch_bounds__(WAVES * 64, 2)
+void match_flagged_kernel(MatchArgs a, const int* __restrict__ flags) {
+    __shared__ __attribute__((aligned(16))) float lds[TileShape<WAVES, NB>::LDS_FLOATS];
+    __shared__ unsigned long long red[WAVES];
+    constexpr int TP = TileShape<WAVES, NB>::TP;
+    const int n_flagged = flags[a.n_search];
+    if (n_flagged == 0) return;
+    const int* __restrict__ list = flags + a.n_search + 2;
+    for (int v = blockIdx.x;; v += gridDim.x) {
+        int acc = 0, found = -1, tin = 0;
+        for (int f = 0; f < n_flagged; ++f) {
+            const int s = list[f];
+            const int nt = (a.searches[s].n_pos + TP - 1) / TP;
+            if (v < acc + nt) { found = s; tin = v - acc; break; }
+            acc += nt;
+        }
+        if (found < 0) break;
+        match_tile<WAVES, NB>(a, found, a.searches[found], tin, lds, red);
+        __syncthreads();
     }
 }
 
@@ -274,6 +264,95 @@ __global__ void unpack_keys_kernel(const unsigned long long* __restrict__ keys, 
 }
 
 // ------------------------------------------------------------------------------------------
+// FFT path, last stage: every position whose f32 FFT score is within `delta` of the search's
+// minimum is re-evaluated exactly (float64 sum of the exact f32*f32 products, float64 prefix
+// sums, cv2's epilogue); the arg-min over those is the result.  One workgroup per search.
+// A search with more than RCAP such positions, or with a block pair that could not list all of
+// its own, is flagged for the direct kernel instead.
+// ------------------------------------------------------------------------------------------
+constexpr int RCAP = 128;
+
+struct RefineArgs {
+    StreamRefs r;
+    const SushiHipSearch* searches;
+    int first_search;
+    int sub_first_pair;
+    const unsigned long long* cand;
+    const unsigned long long* gkeys;
+    float delta;
+    unsigned long long* keys;
+    int* flags;
+    int n_search;
+};
+
+__global__ __launch_bounds__(256)
+void refine_kernel(RefineArgs a) {
+    __shared__ unsigned long long list[RCAP];
+    __shared__ int cnt, ovf;
+    __shared__ double part[4];
+    const int tid = threadIdx.x;
+    const int s_idx = a.first_search + blockIdx.x;
+    const SushiHipSearch sd = a.searches[s_idx];
+    const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
+    if (tid == 0) { cnt = 0; ovf = 0; }
+    __syncthreads();
+    const float thr = key_score(a.gkeys[s_idx]) + a.delta;
+    const unsigned long long* __restrict__ c = a.cand + (size_t)(sd.first_pair - a.sub_first_pair) * (FFT_CAND + 1);
+    const int n_ent = lay.n_pairs * (FFT_CAND + 1);
+    for (int e = tid; e < n_ent; e += 256) {
+        const unsigned long long key = c[e];
+        if (key != NO_KEY && key_score(key) <= thr) {
+            if (key_pos(key) == 0xffffffffu) {
+                ovf = 1;                                   // that pair had more near-minimum positions than slots
+            } else {
+                const int slot = atomicAdd(&cnt, 1);
+                if (slot < RCAP) list[slot] = key; else ovf = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (ovf) {
+        if (tid == 0) {
+            a.flags[s_idx] = 1;
+            const int k = atomicAdd(a.flags + a.n_search, 1);
+            a.flags[a.n_search + 2 + k] = s_idx;
+        }
+        return;                                            // keys[s_idx] stays NO_KEY for the direct kernel
+    }
+    const int n = cnt;
+    const int M = sd.tmpl_len;
+    const TemplStats ts = templ_stats(a.r.src_s1, a.r.src_s2, sd.tmpl_off, M, a.r.centre);
+    const double* __restrict__ w1 = a.r.dst_s1 + sd.win_start;
+    const double* __restrict__ w2 = a.r.dst_s2 + sd.win_start;
+    const float* __restrict__ src = a.r.src_xc + sd.tmpl_off;
+    unsigned long long best = NO_KEY;
+    for (int k = 0; k < n; ++k) {
+        const unsigned p = key_pos(list[k]);
+        const float* __restrict__ d = a.r.dst_xc + sd.win_start + p;
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        int m = tid;
+        for (; m + 768 < M; m += 1024) {
+            acc0 += (double)src[m] * (double)d[m];
+            acc1 += (double)src[m + 256] * (double)d[m + 256];
+            acc2 += (double)src[m + 512] * (double)d[m + 512];
+            acc3 += (double)src[m + 768] * (double)d[m + 768];
+        }
+        for (; m < M; m += 256) acc0 += (double)src[m] * (double)d[m];
+        double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
+        if ((tid & 63) == 0) part[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            const double corr_c = (part[0] + part[1]) + (part[2] + part[3]);
+            const float score = score_at(corr_c, ts, a.r.centre, w1, w2, (int64_t)p, M);
+            const unsigned long long key = make_key(score, p);
+            best = key < best ? key : best;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) a.keys[s_idx] = best;
+}
+
+// ------------------------------------------------------------------------------------------
 // Stream preparation: centred float32 copy + float64 exclusive prefix sums of xc and xc^2.
 // Three passes over blocks of PB samples (block totals -> scan of totals -> in-block scan).
 // ------------------------------------------------------------------------------------------
@@ -284,12 +363,6 @@ constexpr int PB = PB_THREADS * PB_PER_THREAD;   // 4096 samples per block
 template <typename T> __device__ __forceinline__ float centred(T x);
 template <> __device__ __forceinline__ float centred<float>(float x) { return x - 0.5f; }
 template <> __device__ __forceinline__ float centred<uint8_t>(uint8_t x) { return (float)((int)x - 128); }
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
-    return v;
-}
 
 template <typename T>
 __global__ __launch_bounds__(PB_THREADS)
@@ -318,19 +391,6 @@ void centre_blocksum_kernel(const T* __restrict__ raw, int64_t n, float* __restr
         bs1[blockIdx.x] = t1;
         bs2[blockIdx.x] = t2;
     }
-}
-
-// exclusive scan over one wave (64 lanes) of doubles; returns exclusive prefix, *total = wave sum
-__device__ __forceinline__ double wave_excl_scan(double v, double* total) {
-    const int lane = threadIdx.x & 63;
-    double incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
-    }
-    *total = __shfl(incl, 63, 64);
-    return incl - v;
 }
 
 // single workgroup: in-place exclusive scan of the per-block totals
@@ -402,6 +462,45 @@ constexpr Variant kVariants[] = {{1, 1}, {4, 1}, {4, 4}};
 constexpr int kNumVariants = 3;
 
 }  // namespace
+
+namespace sushi {
+
+static MatchArgs match_args(const StreamRefs& r, const SushiHipSearch* searches_dev, int n_search, int n_tiles,
+                            unsigned long long* keys_dev) {
+    MatchArgs a;
+    a.dst_xc = r.dst_xc; a.dst_s1 = r.dst_s1; a.dst_s2 = r.dst_s2; a.dst_len = r.dst_len;
+    a.src_xc = r.src_xc; a.src_s1 = r.src_s1; a.src_s2 = r.src_s2; a.src_len = r.src_len;
+    a.centre = r.centre; a.searches = searches_dev; a.n_search = n_search; a.n_tiles = n_tiles;
+    a.keys = keys_dev;
+    return a;
+}
+
+int launch_refine(const StreamRefs& r, const SushiHipSearch* searches_dev, int first_search, int n_sub,
+                  int sub_first_pair, const unsigned long long* cand_dev, const unsigned long long* gkeys_dev,
+                  float delta, unsigned long long* keys_dev, int* flags_dev, int n_search, hipStream_t st) {
+    RefineArgs a;
+    a.r = r; a.searches = searches_dev; a.first_search = first_search; a.sub_first_pair = sub_first_pair;
+    a.cand = cand_dev; a.gkeys = gkeys_dev; a.delta = delta; a.keys = keys_dev; a.flags = flags_dev;
+    a.n_search = n_search;
+    hipLaunchKernelGGL(refine_kernel, dim3(n_sub), dim3(256), 0, st, a);
+    return launch_ok();
+}
+
+int launch_flagged_direct(const StreamRefs& r, const SushiHipSearch* searches_dev, int n_search,
+                          unsigned long long* keys_dev, const int* flags_dev, hipStream_t st) {
+    const MatchArgs a = match_args(r, searches_dev, n_search, 0, keys_dev);
+    hipLaunchKernelGGL((match_flagged_kernel<4, 4>), dim3(1024), dim3(256), 0, st, a, flags_dev);
+    return launch_ok();
+}
+
+int launch_unpack(const unsigned long long* keys_dev, int n, int32_t* out_idx_dev, float* out_score_dev, hipStream_t st) {
+    hipLaunchKernelGGL(unpack_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, keys_dev, n, out_idx_dev, out_score_dev);
+    return launch_ok();
+}
+
+}  // namespace sushi
+
+using namespace sushi;
 
 extern "C" {
 
@@ -489,20 +588,18 @@ int sushi_hip_match_batch(const float* dst_xc_dev, const double* dst_s1_dev, con
     hipStream_t st = (hipStream_t)hip_stream;
     if (hipMemsetAsync(keys_ws_dev, 0xff, (size_t)n_search * sizeof(uint64_t), st) != hipSuccess)
         return SUSHI_HIP_ELAUNCH;
-    MatchArgs a;
-    a.dst_xc = dst_xc_dev; a.dst_s1 = dst_s1_dev; a.dst_s2 = dst_s2_dev; a.dst_len = dst_len;
-    a.src_xc = src_xc_dev; a.src_s1 = src_s1_dev; a.src_s2 = src_s2_dev; a.src_len = src_len;
-    a.centre = centre; a.searches = searches_dev; a.n_search = n_search; a.n_tiles = n_tiles;
-    a.keys = (unsigned long long*)keys_ws_dev;
+    StreamRefs r;
+    r.dst_xc = dst_xc_dev; r.dst_s1 = dst_s1_dev; r.dst_s2 = dst_s2_dev; r.dst_len = dst_len;
+    r.src_xc = src_xc_dev; r.src_s1 = src_s1_dev; r.src_s2 = src_s2_dev; r.src_len = src_len;
+    r.centre = centre;
+    const MatchArgs a = match_args(r, searches_dev, n_search, n_tiles, (unsigned long long*)keys_ws_dev);
     switch (variant) {
         case 0: hipLaunchKernelGGL((match_sqdiff_f32_kernel<1, 1>), dim3(n_tiles), dim3(64), 0, st, a); break;
         case 1: hipLaunchKernelGGL((match_sqdiff_f32_kernel<4, 1>), dim3(n_tiles), dim3(256), 0, st, a); break;
         default: hipLaunchKernelGGL((match_sqdiff_f32_kernel<4, 4>), dim3(n_tiles), dim3(256), 0, st, a); break;
     }
     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-    hipLaunchKernelGGL(unpack_keys_kernel, dim3((n_search + 255) / 256), dim3(256), 0, st,
-                       (const unsigned long long*)keys_ws_dev, n_search, out_idx_dev, out_score_dev);
-    return launch_ok();
+    return launch_unpack((const unsigned long long*)keys_ws_dev, n_search, out_idx_dev, out_score_dev, st);
 }
 
 }  // extern "C"

@@ -6,6 +6,8 @@ all arithmetic is in libsushi_hip.so.
 * ``SearchBatch``   -- a batch of (pattern, window) descriptors resident in HBM; ``run()`` is one
   pass of the hot path (memset + match kernel + unpack) and nothing else.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -59,9 +61,24 @@ class DeviceStream(object):
             _native.check(rc, "sushi_hip_prepare_stream")
             torch.cuda.current_stream(self.device).synchronize()   # ws/raw may be freed now
         self.raw = raw if keep_raw else None
+        self._spec = None
+
+    def spectra(self):
+        """Block DFTs of this stream for the FFT path (built once, on first use as a search target)."""
+        if self._spec is None:
+            L = _native.lib()
+            nbytes = int(L.sushi_hip_spectra_bytes(self.n))
+            with torch.cuda.device(self.device):
+                spec = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+                rc = L.sushi_hip_prepare_spectra(self.xc.data_ptr(), self.n, spec.data_ptr(), nbytes,
+                                                 _raw_stream(self.device))
+                _native.check(rc, "sushi_hip_prepare_spectra")
+            self._spec = spec
+        return self._spec
 
     def nbytes(self):
-        return self.xc.numel() * 4 + (self.s1.numel() + self.s2.numel()) * 8
+        return self.xc.numel() * 4 + (self.s1.numel() + self.s2.numel()) * 8 + \
+            (0 if self._spec is None else self._spec.numel() * 4)
 
 
 def choose_variant(n_pos, total_waves_wanted=4096):
@@ -77,15 +94,31 @@ def choose_variant(n_pos, total_waves_wanted=4096):
     return best
 
 
+DEFAULT_DELTA = 2e-5            # FFT path: score margin for the exact re-evaluation
+DEFAULT_FFT_WORKSPACE = 1 << 30  # bytes of scratch per batch (sub-batches are sized to fit)
+
+
+def default_path():
+    p = os.environ.get("SUSHI_HIP_PATH", "fft")
+    if p not in ("fft", "direct"):
+        raise SushiError("SUSHI_HIP_PATH must be 'fft' or 'direct'")
+    return p
+
+
 class SearchBatch(object):
     """Descriptors of a batch of searches, resident in HBM, plus the output buffers.
 
     tmpl_off / tmpl_len : pattern = src row [tmpl_off, tmpl_off + tmpl_len)
     win_start / n_pos   : search_source = dst row [win_start, win_start + n_pos + tmpl_len - 1)
     (exactly the two arrays wav.py:184-185 hands to cv2.matchTemplate)
+
+    path = 'fft' (default): overlap-save FFT scores + exact re-evaluation of the near-minimum
+    positions (sushi_hip_match_batch_fft); path = 'direct': the exact-f32 MFMA sliding dot product
+    (sushi_hip_match_batch, `variant` picks its tile size).  Same results either way.
     """
 
-    def __init__(self, dst, src, tmpl_off, tmpl_len, win_start, n_pos, variant=None):
+    def __init__(self, dst, src, tmpl_off, tmpl_len, win_start, n_pos, variant=None, path=None,
+                 delta=DEFAULT_DELTA, workspace_bytes=None):
         if dst.device != src.device:
             raise SushiError("dst and src streams live on different devices")
         if dst.dtype != src.dtype:
@@ -109,7 +142,13 @@ class SearchBatch(object):
         if (n_pos > 0x7fffffff - 65536).any() or (tmpl_len > 0x7fffffff - 65536).any():
             raise SushiError("search too large")
         self.n = n
-        self.variant = choose_variant(n_pos) if variant is None else int(variant)
+        self.path = default_path() if path is None else path
+        if self.path not in ("fft", "direct"):
+            raise SushiError("path must be 'fft' or 'direct'")
+        if self.path == "fft":
+            self.variant = len(_native.variant_tiles()) - 1      # the fallback kernel's tile size
+        else:
+            self.variant = choose_variant(n_pos) if variant is None else int(variant)
         tp = _native.variant_tiles()[self.variant]
         tiles = (n_pos + tp - 1) // tp
         first = np.zeros(n, dtype=np.int64)
@@ -120,6 +159,21 @@ class SearchBatch(object):
         desc = np.zeros(n, dtype=_native.SEARCH_DTYPE)
         desc["tmpl_off"], desc["win_start"] = tmpl_off, win_start
         desc["tmpl_len"], desc["n_pos"], desc["first_tile"] = tmpl_len, n_pos, first
+        if self.path == "fft":
+            pairs, segs = _native.fft_layout(win_start, n_pos, tmpl_len)
+            if pairs.sum() > 0x7fffffff or segs.sum() > 0x7fffffff:
+                raise SushiError("too many blocks in one batch")
+            desc["first_pair"][1:] = np.cumsum(pairs[:-1])
+            desc["first_seg"][1:] = np.cumsum(segs[:-1])
+            L = _native.lib()
+            k_big = int(np.argmax(pairs * 65536 + segs * 65536))
+            need_one = int(L.sushi_hip_fft_workspace_bytes(int(pairs[k_big]), int(segs[k_big])))
+            need_all = int(L.sushi_hip_fft_workspace_bytes(int(pairs.sum()), int(segs.sum())))
+            if workspace_bytes is None:
+                workspace_bytes = int(os.environ.get("SUSHI_HIP_FFT_WS_MB", DEFAULT_FFT_WORKSPACE >> 20)) << 20
+            self.ws_bytes = max(need_one, min(need_all, int(workspace_bytes)))
+            self.delta = float(delta)
+            self.fft_pairs, self.fft_segs = int(pairs.sum()), int(segs.sum())
         self.host_desc = desc
         # algorithmic work of this batch: 2*P*M flop, 4*(P+M-1)+4*M+8 bytes per search
         self.flops = float((2.0 * n_pos.astype(np.float64) * tmpl_len.astype(np.float64)).sum())
@@ -127,15 +181,30 @@ class SearchBatch(object):
         dev = dst.device
         with torch.cuda.device(dev):
             self.desc = torch.from_numpy(desc.view(np.uint8).reshape(-1)).to(dev)
-            self.keys = torch.empty(n, dtype=torch.int64, device=dev)
+            self.keys = torch.empty(2 * n, dtype=torch.int64, device=dev)
             self.out_idx = torch.empty(n, dtype=torch.int32, device=dev)
             self.out_score = torch.empty(n, dtype=torch.float32, device=dev)
+            if self.path == "fft":
+                self.flags = torch.zeros(2 * n + 2, dtype=torch.int32, device=dev)
+                self.ws = torch.empty((self.ws_bytes + 255) // 256 * 64, dtype=torch.float32, device=dev)
+                self.spec = dst.spectra()
 
     def run(self, hip_stream=None):
         """One pass of the hot path over this batch (asynchronous)."""
         L = _native.lib()
         dst, src = self.dst, self.src
         st = _raw_stream(dst.device) if hip_stream is None else hip_stream
+        if self.path == "fft":
+            rc = L.sushi_hip_match_batch_fft(dst.xc.data_ptr(), dst.s1.data_ptr(), dst.s2.data_ptr(), dst.n,
+                                             self.spec.data_ptr(),
+                                             src.xc.data_ptr(), src.s1.data_ptr(), src.s2.data_ptr(), src.n,
+                                             dst.centre, _native.SQDIFF_NORMED,
+                                             self.desc.data_ptr(), self.host_desc.ctypes.data, self.n, self.delta,
+                                             self.ws.data_ptr(), self.ws_bytes,
+                                             self.keys.data_ptr(), self.flags.data_ptr(),
+                                             self.out_idx.data_ptr(), self.out_score.data_ptr(), st)
+            _native.check(rc, "sushi_hip_match_batch_fft")
+            return self.out_idx, self.out_score
         rc = L.sushi_hip_match_batch(dst.xc.data_ptr(), dst.s1.data_ptr(), dst.s2.data_ptr(), dst.n,
                                      src.xc.data_ptr(), src.s1.data_ptr(), src.s2.data_ptr(), src.n,
                                      dst.centre, _native.SQDIFF_NORMED,
@@ -147,3 +216,7 @@ class SearchBatch(object):
     def results(self):
         """(idx int32 ndarray, score float32 ndarray) -- synchronises."""
         return self.out_idx.cpu().numpy(), self.out_score.cpu().numpy()
+
+    def fallback_count(self):
+        """FFT path: how many searches of the last run() were finished by the direct kernel."""
+        return int(self.flags[self.n].item()) if self.path == "fft" else 0

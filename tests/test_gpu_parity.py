@@ -39,13 +39,29 @@ def _check_u8(res_row, idx, score):
     assert np.float32(score).view(np.uint32) == np.float32(res_row[o_idx]).view(np.uint32)
 
 
-def _run_batch(dst_row, src_row, offs, lens, wstart, npos, variant=None):
+PATHS = [0, 1, 2, "fft"]          # direct-kernel variants (tile sizes) and the overlap-save FFT path
+
+
+def _run_batch(dst_row, src_row, offs, lens, wstart, npos, variant=None, want_batch=False, **kw):
+    """variant: 0/1/2 = direct kernel with that tile size, 'fft' = FFT path, None = library default."""
     from sushi_amd.device import DeviceStream, SearchBatch
     dst = DeviceStream(dst_row)
     src = DeviceStream(src_row)
-    b = SearchBatch(dst, src, offs, lens, wstart, npos, variant=variant)
+    if variant == "fft":
+        b = SearchBatch(dst, src, offs, lens, wstart, npos, path="fft", **kw)
+    elif variant is None:
+        b = SearchBatch(dst, src, offs, lens, wstart, npos, **kw)
+    else:
+        b = SearchBatch(dst, src, offs, lens, wstart, npos, variant=variant, path="direct", **kw)
     b.run()
-    return b.results()
+    return (b.results(), b) if want_batch else b.results()
+
+
+@pytest.fixture(params=["fft", "direct"])
+def hip_path(request, monkeypatch):
+    """Runs a drop-in (WavStream) test once per library path."""
+    monkeypatch.setenv("SUSHI_HIP_PATH", request.param)
+    return request.param
 
 
 def test_extension_is_loaded_and_device_is_gfx950():
@@ -74,9 +90,9 @@ def test_prepare_stream(dtype, n):
         np.testing.assert_allclose(g2, s2, rtol=1e-11, atol=1e-9)   # np.cumsum itself rounds sequentially
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", PATHS)
 @pytest.mark.parametrize("dtype", [np.float32, np.uint8])
-@pytest.mark.parametrize("L,M", [(1, 1), (40, 40), (1500, 100), (3000, 700), (20000, 1537), (9000, 4800)])
+@pytest.mark.parametrize("L,M", [(1, 1), (40, 40), (1500, 100), (3000, 700), (20000, 1537), (9000, 4800), (30000, 9000)])
 def test_random_search_vs_oracle(oracle, variant, dtype, L, M):
     rng = np.random.default_rng(L * 31 + M + variant)
     if dtype == np.uint8:
@@ -119,7 +135,7 @@ def test_ragged_batch_all_variants(oracle, dtype):
         offs.append(a); lens.append(m); wst.append(30000); npos.append(60000)
     refs = [oracle.match_template(dst[w:w + p + m - 1], src[o:o + m])[0]
             for o, m, w, p in zip(offs, lens, wst, npos)]
-    for variant in (0, 1, 2, None):
+    for variant in (0, 1, 2, "fft", None):
         idx, score = _run_batch(dst, src, offs, lens, wst, npos, variant)
         for k, res in enumerate(refs):
             (_check_u8 if dtype == np.uint8 else _check_f32)(res, idx[k], score[k])
@@ -127,30 +143,37 @@ def test_ragged_batch_all_variants(oracle, dtype):
             assert idx[40 + k] == 20000 + 1111 * k          # planted copies found exactly
 
 
-def test_planted_copy_ties_and_degenerate(oracle):
+@pytest.mark.parametrize("variant", [2, "fft"])
+def test_planted_copy_ties_and_degenerate(oracle, variant):
+    def run(*args, **kw):
+        return _run_batch(*args, variant=variant, **kw)
+
     rng = np.random.default_rng(1)
     img = rng.random(30000, dtype=np.float32)
     t = img[12345:12345 + 5000].copy()
-    idx, score = _run_batch(img, t, [0], [5000], [0], [25001])
+    idx, score = run(img, t, [0], [5000], [0], [25001])
     assert idx[0] == 12345 and score[0] <= 1e-6
     # exact ties (dyadic floats / uint8): first index wins, like ndarray.argmin (wav.py:186)
     for period in ((rng.integers(0, 64, 50) / 64.0).astype(np.float32), rng.integers(0, 256, 50, dtype=np.uint8)):
         img = np.tile(period, 400)
-        idx, score = _run_batch(img, img, [10], [120], [0], [img.shape[0] - 119])
+        idx, score = run(img, img, [10], [120], [0], [img.shape[0] - 119])
         assert idx[0] == 10 and score[0] == 0.0
-        idx, score = _run_batch(img, img, [10], [120], [23], [img.shape[0] - 119 - 23])
+        idx, score = run(img, img, [10], [120], [23], [img.shape[0] - 119 - 23])
         assert idx[0] == 37 and score[0] == 0.0             # first p with (p + 23) % 50 == 10
     # all-zero windows -> 1.0 (never NaN), all-equal result -> index 0
     z = np.zeros(5000, np.float32)
     t = np.full(100, 0.25, np.float32)
-    idx, score = _run_batch(z, t, [0], [100], [0], [4901])
+    idx, score = run(z, t, [0], [100], [0], [4901])
     assert idx[0] == 0 and score[0] == 1.0
     zu = np.zeros(5000, np.uint8)
-    idx, score = _run_batch(zu, zu, [0], [100], [0], [4901])
+    (idx, score), b = run(zu, zu, [0], [100], [0], [4901], want_batch=True)
     assert idx[0] == 0 and score[0] == 1.0
+    if variant == "fft":
+        assert b.fallback_count() == 1        # 4901 tied positions: finished by the direct kernel
 
 
-def test_halves_identity_on_gpu(oracle):
+@pytest.mark.parametrize("variant", [None, 2])
+def test_halves_identity_on_gpu(oracle, variant):
     """Full / left / right searches of sushi.py:450-452: each one individually matches the oracle."""
     rng = np.random.default_rng(4)
     dst = (rng.standard_normal(80000) * 0.2 + 0.5).clip(0, 1).astype(np.float32)
@@ -158,7 +181,7 @@ def test_halves_identity_on_gpu(oracle):
     k = 6001 // 2
     offs, lens = [0, 0, k], [6001, k, 6001 - k]
     wst, npos = [1000, 1000, 1000 + k], [60000, 60000, 60000]
-    idx, score = _run_batch(dst, src, offs, lens, wst, npos)
+    idx, score = _run_batch(dst, src, offs, lens, wst, npos, variant)
     for j in range(3):
         res = oracle.match_template(dst[wst[j]:wst[j] + npos[j] + lens[j] - 1], src[offs[j]:offs[j] + lens[j]])[0]
         _check_f32(res, idx[j], score[j])
@@ -166,7 +189,7 @@ def test_halves_identity_on_gpu(oracle):
 
 
 @pytest.mark.parametrize("sample_type", ["uint8", "float32"])
-def test_find_substream_dropin_vs_oracle_with_clipping(oracle, sample_type):
+def test_find_substream_dropin_vs_oracle_with_clipping(oracle, sample_type, hip_path):
     """WavStream.find_substream vs the oracle's wav.py:177-188 restatement, including windows
     clipped at both ends of the stream, negative start times and NumPy slice truncation."""
     from sushi_amd import synth
@@ -211,7 +234,7 @@ def test_find_substream_dropin_vs_oracle_with_clipping(oracle, sample_type):
 
 
 @pytest.mark.parametrize("sample_type", ["uint8", "float32"])
-def test_config1_global_offset_recovered(oracle, sample_type, tmp_path):
+def test_config1_global_offset_recovered(oracle, sample_type, tmp_path, hip_path):
     """BASELINE config 0: 50 events, 5-min 12 kHz streams (through real WAV files), +1.5 s offset."""
     import os
     from sushi_amd import synth
@@ -243,7 +266,7 @@ def test_config1_global_offset_recovered(oracle, sample_type, tmp_path):
                 assert _score_ok(diffs[k], rdiff), (diffs[k], rdiff)
 
 
-def test_full_size_windows_properties(oracle):
+def test_full_size_windows_properties(oracle, hip_path):
     """BASELINE config 1 sizes (45-min streams, +-60 s => P = 1,440,001): planted offset recovered
     on every event; a sample of events checked against the FFT oracle."""
     from sushi_amd import synth
@@ -264,3 +287,74 @@ def test_full_size_windows_properties(oracle):
         rdiff, rt = odst.find_substream(pats[k], centres[k], wins[k], matcher=oracle.match_template_fft)
         assert abs(times[k] - rt) <= 1.0 / 12000 + 1e-12
         assert _score_ok(diffs[k], rdiff), (diffs[k], rdiff)
+
+
+# ----------------------------------------------------------------------------------------------
+# FFT path specifics
+# ----------------------------------------------------------------------------------------------
+
+def test_fft_spectra_match_numpy():
+    """sushi_hip_prepare_spectra: block j = DFT_8192(xc[jB..jB+2B) + i*xc[(j+1)B..(j+3)B)), zeros past the end."""
+    from sushi_amd import _native
+    from sushi_amd.device import DeviceStream
+    rng = np.random.default_rng(3)
+    n = 5 * 4096 + 1234
+    x = rng.random(n, dtype=np.float32)
+    d = DeviceStream(x)
+    hop = _native.lib().sushi_hip_fft_hop()
+    assert hop == 4096
+    spec = d.spectra().cpu().numpy().view(np.complex64).reshape(-1, 2 * hop)
+    assert spec.shape[0] == _native.lib().sushi_hip_spectra_blocks(n) == 6
+    xc = np.zeros(10 * hop, np.float64)
+    xc[:n] = x.astype(np.float64) - 0.5
+    for j in range(spec.shape[0]):
+        ref = np.fft.fft(xc[j * hop:(j + 2) * hop] + 1j * xc[(j + 1) * hop:(j + 3) * hop])
+        err = np.abs(spec[j] - ref).max() / np.abs(ref).max()
+        assert err < 2e-6, (j, err)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint8])
+def test_fft_long_template_stream_end_and_subbatches(oracle, dtype):
+    """Templates longer than 16 segments (chunked accumulate), windows that run into the end of the
+    stream (zero blocks), and a workspace so small that the batch is split into many sub-batches:
+    all identical to the oracle / to the one-sub-batch run."""
+    rng = np.random.default_rng(17)
+    n_dst, n_src = 400000, 120000
+    if dtype == np.uint8:
+        dst = rng.integers(0, 256, n_dst, dtype=np.uint8)
+        src = rng.integers(0, 256, n_src, dtype=np.uint8)
+    else:
+        dst = (rng.standard_normal(n_dst) * 0.2 + 0.5).clip(0, 1).astype(np.float32)
+        src = (rng.standard_normal(n_src) * 0.2 + 0.5).clip(0, 1).astype(np.float32)
+    src[1000:1000 + 70000] = dst[250000:320000]                 # a 70,000-sample (18-segment) planted copy
+    offs = [1000, 1000, 500, 90000, 3, 40000]
+    lens = [70000, 70000, 66000, 25000, 4097, 8192]
+    wst = [200000, 0, 100000, 360000, 390000, 395000 - 8192]
+    npos = [n_dst - 200000 - 70000 + 1, 300001, 150000, n_dst - 360000 - 25000 + 1, n_dst - 390000 - 4097 + 1, 5001]
+    (idx, score), b = _run_batch(dst, src, offs, lens, wst, npos, "fft", want_batch=True)
+    assert idx[0] == 50000 and idx[1] == 250000
+    chk = _check_u8 if dtype == np.uint8 else _check_f32
+    for k in range(len(offs)):
+        res = oracle.match_template(dst[wst[k]:wst[k] + npos[k] + lens[k] - 1], src[offs[k]:offs[k] + lens[k]])[0]
+        chk(res, idx[k], score[k])
+    # the same batch through the smallest workspace the library accepts -> one search per sub-batch
+    (idx2, score2), b2 = _run_batch(dst, src, offs, lens, wst, npos, "fft", want_batch=True, workspace_bytes=1)
+    assert b2.ws_bytes < b.ws_bytes
+    assert (idx2 == idx).all() and (score2.view(np.uint32) == score.view(np.uint32)).all()
+    # and the direct kernel agrees bit for bit on uint8 (exact integers on both paths)
+    idx3, score3 = _run_batch(dst, src, offs, lens, wst, npos, 2)
+    if dtype == np.uint8:
+        assert (idx3 == idx).all() and (score3.view(np.uint32) == score.view(np.uint32)).all()
+
+
+def test_fft_near_ties_fall_back_to_direct(oracle):
+    """Smooth / periodic streams put many positions within `delta` of the minimum: the refinement
+    flags the search and the direct kernel finishes it -- first index of the exact minimum."""
+    t = np.arange(60000, dtype=np.float64)
+    img = (0.5 + 0.3 * np.sin(2 * np.pi * t / 5000.0)).astype(np.float32)       # very smooth
+    tpl = img[20000:26000].copy()
+    (idx, score), b = _run_batch(img, tpl, [0], [6000], [0], [54001], "fft", want_batch=True)
+    res = oracle.match_template(img, tpl)[0]
+    _check_f32(res, idx[0], score[0])
+    idx_d, score_d = _run_batch(img, tpl, [0], [6000], [0], [54001], 2)
+    assert idx_d[0] == idx[0] and np.float32(score_d[0]) == np.float32(score[0])

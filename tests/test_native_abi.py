@@ -14,7 +14,7 @@ def test_library_builds_and_exports_all_declared_symbols():
     assert os.path.exists(path)
     lib = ctypes.CDLL(path)
     declared = _native.declared_symbols()
-    assert len(declared) >= 9
+    assert len(declared) >= 18
     for name in declared:
         assert hasattr(lib, name), name
     out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
@@ -24,7 +24,7 @@ def test_library_builds_and_exports_all_declared_symbols():
 
 def test_host_only_entry_points():
     L = _native.lib()
-    assert L.sushi_hip_abi_version() == 1
+    assert L.sushi_hip_abi_version() == 2
     assert L.sushi_hip_strerror(0) == b"ok" and b"invalid" in L.sushi_hip_strerror(-1)
     assert _native.variant_tiles() == [1024, 4096, 16384]
     assert L.sushi_hip_variant_tile_positions(99) == -1
@@ -35,6 +35,30 @@ def test_host_only_entry_points():
     assert L.sushi_hip_prepare_stream(None, 1, 10, None, None, None, None, 0, None) == -1
     assert L.sushi_hip_match_batch(None, None, None, 0, None, None, None, 0, 0.5, 0, None, 0, 0, 0,
                                    None, None, None, None) == -1
+    # FFT path: layout helpers are pure host arithmetic
+    import ctypes as C
+    assert L.sushi_hip_fft_hop() == 4096
+    assert L.sushi_hip_spectra_blocks(1) == 1 and L.sushi_hip_spectra_blocks(4096) == 1
+    assert L.sushi_hip_spectra_blocks(4097) == 2 and L.sushi_hip_spectra_blocks(0) == 0
+    assert L.sushi_hip_spectra_bytes(4097) == 2 * 8192 * 8
+    pairs, segs = C.c_int32(), C.c_int32()
+    assert L.sushi_hip_fft_layout(0, 1, 1, C.byref(pairs), C.byref(segs)) == 0
+    assert (pairs.value, segs.value) == (1, 1)
+    assert L.sushi_hip_fft_layout(4095, 2, 4097, C.byref(pairs), C.byref(segs)) == 0
+    assert (pairs.value, segs.value) == (1, 2)                 # positions 4095, 4096 -> blocks 0 and 1 -> one pair
+    assert L.sushi_hip_fft_layout(4095, 4098, 36000, C.byref(pairs), C.byref(segs)) == 0
+    assert (pairs.value, segs.value) == (2, 9)                 # blocks 0..2 -> two pairs
+    assert L.sushi_hip_fft_layout(-1, 1, 1, C.byref(pairs), C.byref(segs)) == -1
+    for w, p, m in [(0, 1, 1), (4095, 2, 4097), (123456, 1440001, 36000), (8192, 4096, 65537)]:
+        assert L.sushi_hip_fft_layout(w, p, m, C.byref(pairs), C.byref(segs)) == 0
+        vp, vs = _native.fft_layout([w], [p], [m])
+        assert (int(vp[0]), int(vs[0])) == (pairs.value, segs.value)
+    assert L.sushi_hip_fft_workspace_bytes(1, 1) == 65536 + 65536 + 256
+    assert L.sushi_hip_prepare_spectra(None, 10, None, 0, None) == -1
+    assert L.sushi_hip_match_batch_fft(None, None, None, 0, None, None, None, None, 0, 0.5, 0, None, None, 0, 2e-5,
+                                       None, 0, None, None, None, None, None) == -1
+    n = C.c_int(-1)
+    assert L.sushi_hip_profile_end(None, 0, C.byref(n)) == -1
 
 
 def test_descriptor_layout_matches_header(tmp_path):
@@ -42,13 +66,15 @@ def test_descriptor_layout_matches_header(tmp_path):
     exe = os.path.join(tmp_path, "layout")
     with open(src, "w") as f:
         f.write('#include <stdio.h>\n#include <stddef.h>\n#include "sushi_hip.h"\n'
-                'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(SushiHipSearch),'
+                'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(SushiHipSearch),'
                 'offsetof(SushiHipSearch,tmpl_off),offsetof(SushiHipSearch,win_start),'
                 'offsetof(SushiHipSearch,tmpl_len),offsetof(SushiHipSearch,n_pos),'
-                'offsetof(SushiHipSearch,first_tile));return 0;}\n')
+                'offsetof(SushiHipSearch,first_tile),offsetof(SushiHipSearch,first_pair),'
+                'offsetof(SushiHipSearch,first_seg));return 0;}\n')
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
     subprocess.check_call(["gcc", "-std=c99", "-I", inc, src, "-o", exe])     # header is plain C
     vals = [int(x) for x in subprocess.check_output([exe]).split()]
     d = _native.SEARCH_DTYPE
     assert vals == [d.itemsize, d.fields["tmpl_off"][1], d.fields["win_start"][1], d.fields["tmpl_len"][1],
-                    d.fields["n_pos"][1], d.fields["first_tile"][1]]
+                    d.fields["n_pos"][1], d.fields["first_tile"][1], d.fields["first_pair"][1],
+                    d.fields["first_seg"][1]]
