@@ -114,7 +114,8 @@ SUSHI_HIP_API int sushi_hip_match_batch(const float* dst_xc_dev, const double* d
 /* ---- overlap-save FFT path ------------------------------------------------------------------
  * The destination stream is cut into blocks of sushi_hip_fft_hop() = B samples; block j is
  * stored as the 2B-point complex DFT of xc[jB .. jB+2B) + i * xc[(j+1)B .. (j+3)B) (zeros past
- * the end), 2B complex float32 each: sushi_hip_spectra_bytes(n) = ceil(n/B) * 2B * 8 bytes.
+ * the end), 2B complex float32 each, followed by one all-zero block:
+ * sushi_hip_spectra_bytes(n) = (ceil(n/B) + 1) * 2B * 8 bytes.
  * A search covers the blocks floor(win_start/B) .. floor((win_start+n_pos-1)/B), two per
  * "pair", and its template is cut into ceil(tmpl_len/B) segments. */
 SUSHI_HIP_API int sushi_hip_fft_hop(void);

@@ -11,7 +11,7 @@ import numpy as np
 from .common import SushiError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsushi_hip.so")
+LIB_PATH = os.environ.get("SUSHI_HIP_LIB") or os.path.join(_HERE, "lib", "libsushi_hip.so")   # env: dev A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sushi_hip.h")
 
 # dtype codes (include/sushi_hip.h)

@@ -22,7 +22,10 @@ COMMON_DEPS = [HEADER, os.path.join(CSRC, "sushi_common.hpp"), os.path.join(CSRC
 # a*b-c*d would round differently from the reference (the hot loop is MFMA builtins, unaffected).
 UNITS = [
     ("sushi_hip", ["-ffp-contract=off"], []),
-    ("sushi_fft", [], [os.path.join(CSRC, "fft_core.hpp"), os.path.join(CSRC, "mac_core.hpp"), TWIDDLE_INC]),
+    # -fno-slp-vectorize: the SLP pass packs the complex MACs into v_pk_fma_f32 and pays for it in
+    # register shuffles (v_mov / accvgpr traffic); plain v_fma_f32 already issues at the f32 peak rate.
+    ("sushi_fft", ["-fno-slp-vectorize"],
+     [os.path.join(CSRC, "fft_core.hpp"), os.path.join(CSRC, "mac_core.hpp"), TWIDDLE_INC]),
 ]
 
 

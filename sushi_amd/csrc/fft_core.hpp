@@ -79,24 +79,36 @@ struct Dft<1, DIR> {
     static SUSHI_HD void run(cpx*) {}
 };
 
-// One pass, register side: twiddle (unless NS == 1) and butterfly the PER points of this thread.
-// v[b*R + t] holds input t of butterfly j = tid + b*NT.
+// Base twiddles of the three twiddled passes for this thread, w^1 = exp(DIR*2*pi*i*k/(NS*R)) with
+// k = j mod NS: the two butterflies of a thread (j = tid, tid + 512) share k in passes 2 and 3.
 // tw[n] = exp(-2*pi*i*n/N), n = 0..N-1 (the forward table; the inverse conjugates it).
+// Loaded once, before the first barrier, so that no table load sits between two passes.
+struct Twiddles { cpx p2, p3, p4a, p4b; };
+
+template <int DIR>
+SUSHI_HD Twiddles load_twiddles(int tid, const cpx* __restrict__ tw) {
+    Twiddles t;
+    t.p2 = tw[(tid & 15) * (N / 128)];
+    t.p3 = tw[(tid & 127) * (N / 1024)];
+    t.p4a = tw[tid];
+    t.p4b = tw[tid + NT];
+    if (DIR > 0) { t.p2 = cconj(t.p2); t.p3 = cconj(t.p3); t.p4a = cconj(t.p4a); t.p4b = cconj(t.p4b); }
+    return t;
+}
+
+// One pass, register side: twiddle (unless NS == 1) and butterfly the PER points of this thread.
+// v[b*R + t] holds input t of butterfly j = tid + b*NT; w1[b] is that butterfly's base twiddle.
 template <int R, int NS, int DIR>
-SUSHI_HD void pass_compute(cpx* v, int tid, const cpx* __restrict__ tw) {
+SUSHI_HD void pass_compute(cpx* v, const cpx* w1) {
     constexpr int NB = PER / R;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         cpx* x = v + b * R;
         if (NS > 1) {
-            const int j = tid + b * NT;
-            const int k = j & (NS - 1);
-            cpx w1 = tw[k * (N / (NS * R))];
-            if (DIR > 0) w1 = cconj(w1);
             cpx w[R];
-            w[1] = w1;
+            w[1] = w1[b];
 #pragma unroll
-            for (int t = 2; t < R; ++t) w[t] = (t & 1) ? cmul(w[t - 1], w1) : cmul(w[t / 2], w[t / 2]);
+            for (int t = 2; t < R; ++t) w[t] = (t & 1) ? cmul(w[t - 1], w[1]) : cmul(w[t / 2], w[t / 2]);
 #pragma unroll
             for (int t = 1; t < R; ++t) x[t] = cmul(x[t], w[t]);
         }
@@ -142,22 +154,23 @@ SUSHI_HD int out_index(int tid, int r) { return tid + NT * ((r >> 3) + 2 * (r & 
 // `lds` must hold LDS_ELEMS elements; contents are dead after the call's last barrier... the buffer may be
 // reused by the caller after one further __syncthreads().
 template <int DIR>
-__device__ __forceinline__ void fft8192(cpx* v, int tid, cpx* lds, const cpx* __restrict__ tw) {
-    pass_compute<16, 1, DIR>(v, tid, tw);
+__device__ __forceinline__ void fft8192(cpx* v, int tid, cpx* lds, const Twiddles tw) {
+    const cpx w2[2] = {tw.p2, tw.p2}, w3[2] = {tw.p3, tw.p3}, w4[2] = {tw.p4a, tw.p4b};
+    pass_compute<16, 1, DIR>(v, nullptr);
     pass_store<16, 1>(v, tid, lds);
     SUSHI_FFT_BARRIER();
     pass_load<8>(v, tid, lds);
-    pass_compute<8, 16, DIR>(v, tid, tw);
+    pass_compute<8, 16, DIR>(v, w2);
     SUSHI_FFT_BARRIER();
     pass_store<8, 16>(v, tid, lds);
     SUSHI_FFT_BARRIER();
     pass_load<8>(v, tid, lds);
-    pass_compute<8, 128, DIR>(v, tid, tw);
+    pass_compute<8, 128, DIR>(v, w3);
     SUSHI_FFT_BARRIER();
     pass_store<8, 128>(v, tid, lds);
     SUSHI_FFT_BARRIER();
     pass_load<8>(v, tid, lds);
-    pass_compute<8, 1024, DIR>(v, tid, tw);
+    pass_compute<8, 1024, DIR>(v, w4);
 }
 #endif
 

@@ -49,6 +49,8 @@ int main() {
             worst = std::fmax(worst, run<16>(s, p, 1 << 30));
             worst = std::fmax(worst, run<16>(s, p, 2 * p - 1));      // stream ends inside the window
             worst = std::fmax(worst, run<2>(s, p, 1 << 30));
+            worst = std::fmax(worst, run<4>(s, p, 1 << 30));
+            worst = std::fmax(worst, run<12>(s, p, 2 * p + 3));
         }
     printf("%.3e\n", worst);
     return worst < 1e-5 ? 0 : 1;

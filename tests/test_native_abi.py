@@ -40,7 +40,7 @@ def test_host_only_entry_points():
     assert L.sushi_hip_fft_hop() == 4096
     assert L.sushi_hip_spectra_blocks(1) == 1 and L.sushi_hip_spectra_blocks(4096) == 1
     assert L.sushi_hip_spectra_blocks(4097) == 2 and L.sushi_hip_spectra_blocks(0) == 0
-    assert L.sushi_hip_spectra_bytes(4097) == 2 * 8192 * 8
+    assert L.sushi_hip_spectra_bytes(4097) == 3 * 8192 * 8 and L.sushi_hip_spectra_bytes(0) == 0
     pairs, segs = C.c_int32(), C.c_int32()
     assert L.sushi_hip_fft_layout(0, 1, 1, C.byref(pairs), C.byref(segs)) == 0
     assert (pairs.value, segs.value) == (1, 1)
