@@ -9,3 +9,10 @@ class SushiError(Exception):
 def clip(value, minimum, maximum):
     """common.py:41-42"""
     return max(min(value, maximum), minimum)
+
+
+def format_time(seconds):
+    """common.py:31-38 (h:mm:ss.cc, as in the reference's log lines)"""
+    cs = round(seconds * 100)
+    return u'{0}:{1:02d}:{2:02d}.{3:02d}'.format(int(cs // 360000), int((cs // 6000) % 60),
+                                                 int((cs // 100) % 60), int(cs % 100))

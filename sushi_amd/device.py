@@ -95,7 +95,7 @@ def choose_variant(n_pos, total_waves_wanted=4096):
 
 
 DEFAULT_DELTA = 2e-5            # FFT path: score margin for the exact re-evaluation
-DEFAULT_FFT_WORKSPACE = 1 << 30  # bytes of scratch per batch (sub-batches are sized to fit)
+DEFAULT_FFT_WORKSPACE = 16 << 30  # bytes of scratch per batch at most (sub-batches are sized to fit; 288 GB HBM)
 
 
 def default_path():

@@ -254,9 +254,10 @@ class WavStream(object):
         lo, hi, _ = slice(start_sample, end_sample).indices(self.data.shape[1])   # NumPy slice truncation
         return start_time, lo, max(hi - lo, 0) - pattern_len + 1
 
-    def find_substreams(self, patterns, window_centers, window_sizes):
+    def find_substreams(self, patterns, window_centers, window_sizes, with_index=False):
         """[find_substream(p, c, w) for p, c, w in zip(...)] in one GPU launch.
-        Returns (diffs: float32 ndarray, times: list of float)."""
+        Returns (diffs: float32 ndarray, times: list of float); with_index=True appends the absolute
+        sample index of every match in self.data (what SpeculativeStream caches)."""
         from .device import DeviceStream, SearchBatch
         n = len(patterns)
         if not (len(window_centers) == len(window_sizes) == n) or n == 0:
@@ -293,4 +294,6 @@ class WavStream(object):
         batch.run()
         idx, score = batch.results()
         times = [st + (int(k) / float(self.sample_rate)) for st, k in zip(start_times, idx)]
+        if with_index:
+            return score, times, [int(lo) + int(k) for lo, k in zip(win_start, idx)]
         return score, times
