@@ -116,29 +116,36 @@ SUSHI_HD void pass_compute(cpx* v, const cpx* w1) {
     }
 }
 
-// store the outputs of a pass into the (padded) LDS buffer
+// store the outputs of a pass into the (padded) LDS buffer.  pad(base + t*NS) is written as
+// pad(base) + t*(NS + NS/16) (exact when NS is a multiple of 16; for NS = 1, base = 16 j and
+// pad(16 j + t) = 17 j + t) so that every access is one address register plus an immediate offset.
 template <int R, int NS>
 SUSHI_HD void pass_store(const cpx* v, int tid, cpx* lds) {
     constexpr int NB = PER / R;
+    static_assert(NS == 1 || NS % 16 == 0, "padding arithmetic assumes NS = 1 or a multiple of 16");
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int j = tid + b * NT;
         const int k = j & (NS - 1);
         const int base = (j - k) * R + k;
+        cpx* out = lds + (NS == 1 ? base + j : pad(base));
 #pragma unroll
-        for (int t = 0; t < R; ++t) lds[pad(base + t * NS)] = v[b * R + t];
+        for (int t = 0; t < R; ++t) out[NS == 1 ? t : t * (NS + NS / 16)] = v[b * R + t];
     }
 }
 
-// load the inputs of a radix-R pass from the LDS buffer
+// load the inputs of a radix-R pass from the LDS buffer: pad(j + t*N/R) = pad(j) + t*(N/R + N/R/16)
 template <int R>
 SUSHI_HD void pass_load(cpx* v, int tid, const cpx* lds) {
     constexpr int NB = PER / R;
+    constexpr int STRIDE = N / R;
+    static_assert(STRIDE % 16 == 0, "padding arithmetic assumes N/R is a multiple of 16");
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int j = tid + b * NT;
+        const cpx* in = lds + pad(j);
 #pragma unroll
-        for (int t = 0; t < R; ++t) v[b * R + t] = lds[pad(j + t * (N / R))];
+        for (int t = 0; t < R; ++t) v[b * R + t] = in[t * (STRIDE + STRIDE / 16)];
     }
 }
 
@@ -153,8 +160,12 @@ SUSHI_HD int out_index(int tid, int r) { return tid + NT * ((r >> 3) + 2 * (r & 
 // Full transform of the 16 points in v (in_index layout) -> v (out_index layout).
 // `lds` must hold LDS_ELEMS elements; contents are dead after the call's last barrier... the buffer may be
 // reused by the caller after one further __syncthreads().
-template <int DIR>
-__device__ __forceinline__ void fft8192(cpx* v, int tid, cpx* lds, const Twiddles tw) {
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `before_last_pass` runs after the third pass's stores and before the last pass: a place to issue
+// independent global loads whose latency the last pass then covers.
+template <int DIR, class Hook = NoHook>
+__device__ __forceinline__ void fft8192(cpx* v, int tid, cpx* lds, const Twiddles tw, Hook before_last_pass = Hook()) {
     const cpx w2[2] = {tw.p2, tw.p2}, w3[2] = {tw.p3, tw.p3}, w4[2] = {tw.p4a, tw.p4b};
     pass_compute<16, 1, DIR>(v, nullptr);
     pass_store<16, 1>(v, tid, lds);
@@ -168,6 +179,7 @@ __device__ __forceinline__ void fft8192(cpx* v, int tid, cpx* lds, const Twiddle
     pass_compute<8, 128, DIR>(v, w3);
     SUSHI_FFT_BARRIER();
     pass_store<8, 128>(v, tid, lds);
+    before_last_pass();
     SUSHI_FFT_BARRIER();
     pass_load<8>(v, tid, lds);
     pass_compute<8, 1024, DIR>(v, w4);
