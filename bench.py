@@ -232,8 +232,20 @@ def main():
             kname = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "ifft_kernel",
                      "refine": "refine_kernel", "finish": "match_flagged_kernel+unpack_keys_kernel"}[dom]
             achieved = batch.algorithmic_bytes / (dom_ms * 1e-3) / 1e9
+            # HBM bytes of that kernel per launch from the committed rocprofv3 PMC passes of this very
+            # workload (profiles/pmc_traffic.json, made by tools/make_pmc_traffic.py); None if absent
+            traffic, traffic_bytes = None, None
+            wl_key = "configs1/fft/%s/%d/w%g/m%g" % (args.sample_type, args.events, args.window, args.minutes)
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    kern = json.load(f)[wl_key]["kernels"][kname]
+                traffic_bytes = kern["fetch_bytes"] + kern["write_bytes"]
+                traffic = traffic_bytes / (dom_ms * 1e-3) / 1e9
+            except Exception:
+                pass
             roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                        "frac": achieved / PEAK_HBM_GBPS, "traffic": None,
+                        "frac": achieved / PEAK_HBM_GBPS, "traffic": traffic,
+                        "traffic_bytes_per_launch": traffic_bytes, "traffic_key": wl_key,
                         "kernel": kname, "kernel_ms": dom_ms, "stage_ms": stages,
                         "step_kernels_ms": kernel_ms,
                         "step_hbm_achieved_GBps": batch.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9,

@@ -123,9 +123,10 @@ SUSHI_HIP_API int64_t sushi_hip_spectra_blocks(int64_t n);
 SUSHI_HIP_API size_t sushi_hip_spectra_bytes(int64_t n);
 SUSHI_HIP_API int sushi_hip_fft_layout(int64_t win_start, int32_t n_pos, int32_t tmpl_len,
                                        int32_t* n_pairs, int32_t* n_seg);
-/* Workspace needed to run one search of that shape (the call splits a batch into sub-batches
- * that fit the workspace it is given; more workspace = fewer, larger launches). */
-SUSHI_HIP_API size_t sushi_hip_fft_workspace_bytes(int32_t n_pairs, int32_t n_seg);
+/* Workspace needed to run n_search searches with n_pairs block pairs and n_seg template segments in
+ * total as ONE sub-batch (the call splits a batch into sub-batches that fit the workspace it is given;
+ * more workspace = fewer, larger launches; the minimum is what the largest single search needs). */
+SUSHI_HIP_API size_t sushi_hip_fft_workspace_bytes(int64_t n_pairs, int64_t n_seg, int64_t n_search);
 
 /* xc_dev: centred stream from sushi_hip_prepare_stream (16-byte aligned); spec_dev: output. */
 SUSHI_HIP_API int sushi_hip_prepare_spectra(const float* xc_dev, int64_t n, void* spec_dev, size_t spec_bytes,
@@ -137,7 +138,7 @@ SUSHI_HIP_API int sushi_hip_prepare_spectra(const float* xc_dev, int64_t n, void
  *                       first_tile must be laid out for variant sushi_hip_variant_count()-1,
  *                       first_pair / first_seg as running sums of sushi_hip_fft_layout()
  *   delta             : score margin (> 2x the FFT error; 2e-5 is ample for WavStream data)
- *   ws_dev / ws_bytes : scratch, >= sushi_hip_fft_workspace_bytes of the largest search
+ *   ws_dev / ws_bytes : scratch, >= sushi_hip_fft_workspace_bytes(pairs, segments, 1) of the largest search
  *   keys_ws_dev       : uint64[2 * n_search] scratch
  *   flags_dev         : int32[2 * n_search + 2] scratch; on completion flags[k] = 1 if search k had too
  *                       many near-ties and was finished by the direct kernel, flags[n_search] = how many */

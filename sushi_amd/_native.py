@@ -76,7 +76,7 @@ def lib():
     L.sushi_hip_fft_layout.restype = ci
     L.sushi_hip_fft_layout.argtypes = [i64, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.sushi_hip_fft_workspace_bytes.restype = sz
-    L.sushi_hip_fft_workspace_bytes.argtypes = [i32, i32]
+    L.sushi_hip_fft_workspace_bytes.argtypes = [i64, i64, i64]
     L.sushi_hip_prepare_spectra.restype = ci
     L.sushi_hip_prepare_spectra.argtypes = [vp, i64, vp, sz, vp]
     L.sushi_hip_match_batch_fft.restype = ci

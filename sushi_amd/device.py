@@ -167,8 +167,8 @@ class SearchBatch(object):
             desc["first_seg"][1:] = np.cumsum(segs[:-1])
             L = _native.lib()
             k_big = int(np.argmax(pairs * 65536 + segs * 65536))
-            need_one = int(L.sushi_hip_fft_workspace_bytes(int(pairs[k_big]), int(segs[k_big])))
-            need_all = int(L.sushi_hip_fft_workspace_bytes(int(pairs.sum()), int(segs.sum())))
+            need_one = int(L.sushi_hip_fft_workspace_bytes(int(pairs[k_big]), int(segs[k_big]), 1))
+            need_all = int(L.sushi_hip_fft_workspace_bytes(int(pairs.sum()), int(segs.sum()), n))
             if workspace_bytes is None:
                 workspace_bytes = int(os.environ.get("SUSHI_HIP_FFT_WS_MB", DEFAULT_FFT_WORKSPACE >> 20)) << 20
             self.ws_bytes = max(need_one, min(need_all, int(workspace_bytes)))

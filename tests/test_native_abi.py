@@ -53,7 +53,8 @@ def test_host_only_entry_points():
         assert L.sushi_hip_fft_layout(w, p, m, C.byref(pairs), C.byref(segs)) == 0
         vp, vs = _native.fft_layout([w], [p], [m])
         assert (int(vp[0]), int(vs[0])) == (pairs.value, segs.value)
-    assert L.sushi_hip_fft_workspace_bytes(1, 1) == 65536 + 65536 + 3 * 256
+    assert L.sushi_hip_fft_workspace_bytes(1, 1, 1) == 65536 + 65536 + 3 * 256
+    assert L.sushi_hip_fft_workspace_bytes(176555, 9379, 1000) > L.sushi_hip_fft_workspace_bytes(176555, 9379, 1)
     assert L.sushi_hip_prepare_spectra(None, 10, None, 0, None) == -1
     assert L.sushi_hip_match_batch_fft(None, None, None, 0, None, None, None, None, 0, 0.5, 0, None, None, 0, 2e-5,
                                        None, 0, None, None, None, None, None) == -1
