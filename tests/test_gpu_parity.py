@@ -359,3 +359,53 @@ def test_fft_near_ties_fall_back_to_direct(oracle):
     _check_f32(res, idx[0], score[0])
     idx_d, score_d = _run_batch(img, tpl, [0], [6000], [0], [54001], 2)
     assert idx_d[0] == idx[0] and np.float32(score_d[0]) == np.float32(score[0])
+
+
+def _planted_config(seconds, rate, window, n_events, off_s, seed, n_oracle, oracle, min_len=1.0, max_len=5.0):
+    """Shared body of the full-size configuration tests: planted offset recovered on every event
+    (size-independent property), a few events checked against the FFT oracle, both library paths agree."""
+    from sushi_amd import synth
+    from sushi_amd.device import SearchBatch
+    from sushi_amd.wav import WavStream
+    dst_pcm = synth.make_dst_pcm(seconds, rate, seed=seed)
+    src_pcm = synth.make_src_pcm(dst_pcm, int(off_s * rate), seed=seed + 1)
+    dst = WavStream.from_samples(dst_pcm, rate, sample_rate=rate, sample_type="float32")
+    src = WavStream.from_samples(src_pcm, rate, sample_rate=rate, sample_type="float32")
+    del dst_pcm, src_pcm
+    events = synth.make_events(n_events, seconds, window + off_s, seed=seed + 2, min_len=min_len, max_len=max_len)
+    pats, centres, wins = synth.explicit_descriptors(src, dst, events, off_s, window, seed=seed + 3)
+    diffs, times, positions = dst.find_substreams(pats, centres, wins, with_index=True)        # FFT path
+    for k, (s, e) in enumerate(events):
+        assert abs((times[k] - s) - off_s) <= 1.0 / rate + 1e-9, (k, times[k] - s)
+        assert 0.0 <= diffs[k] < 0.05
+    odst = oracle.OracleWavStream(dst.data, dst.sample_rate, dst.sample_count, dst.padding_size)
+    for k in list(range(n_events))[:: max(1, n_events // n_oracle)][:n_oracle]:
+        rdiff, rt = odst.find_substream(pats[k], centres[k], wins[k], matcher=oracle.match_template_fft)
+        assert abs(times[k] - rt) <= 1.0 / rate + 1e-12
+        assert _score_ok(diffs[k], rdiff), (diffs[k], rdiff)
+    # the direct kernel on a couple of the same searches: same position, same float32 score
+    sel = [0, n_events - 1]
+    offs = [src._get_sample_for_time(events[k][0]) for k in sel]
+    lens = [pats[k].shape[1] for k in sel]
+    wst, npos = [], []
+    for k in sel:
+        _, lo, p = dst._window(pats[k].shape[1], centres[k], wins[k])
+        wst.append(lo); npos.append(p)
+    b = SearchBatch(dst.device_stream(), src.device_stream(), offs, lens, wst, npos, path="direct")
+    b.run()
+    idx_d, score_d = b.results()
+    for j, k in enumerate(sel):
+        assert wst[j] + int(idx_d[j]) == positions[k]
+        assert abs(float(score_d[j]) - float(diffs[k])) <= 2.5e-7
+
+
+def test_config3_sizes_two_hour_streams_120s_window(oracle):
+    """BASELINE configs[2] sizes: 2-h 12 kHz streams, +-120 s (P = 2,880,001); one rank's worth of events
+    is 375 -- 48 here."""
+    _planted_config(7200, 12000, 120, 48, 11.5, seed=31, n_oracle=2, oracle=oracle)
+
+
+def test_config5_sizes_24khz_four_hour_streams(oracle):
+    """BASELINE configs[4] sizes: 4-h 24 kHz streams (346 M samples, 5.5 GB of block spectra), +-120 s
+    (P = 5,760,001), templates up to 5 s = 120,000 samples = 30 segments (two multiply-accumulate chunks)."""
+    _planted_config(14400, 24000, 120, 8, -17.25 + 40.0, seed=41, n_oracle=1, oracle=oracle, min_len=3.0, max_len=5.0)
