@@ -120,6 +120,9 @@ def main():
     from sushi_amd.wav import WavStream
 
     # ---- synthetic inputs (identical on every rank: streams are replicated) ---------------------
+    # The streams are built with the NumPy load pipeline: the CPU baseline below forks worker processes,
+    # which must happen before this process initialises HIP (the GPU load pipeline would do that).
+    os.environ["SUSHI_HIP_LOAD"] = "host"
     seconds = args.minutes * 60.0
     seed = 20260924 + 1
     dst_pcm = synth.make_dst_pcm(seconds, args.rate, seed=seed)

@@ -152,6 +152,25 @@ SUSHI_HIP_API int sushi_hip_match_batch_fft(const float* dst_xc_dev, const doubl
                               uint64_t* keys_ws_dev, int32_t* flags_dev,
                               int32_t* out_idx_dev, float* out_score_dev, void* hip_stream);
 
+/* ---- WavStream.__init__ value pipeline on the GPU (wav.py:113-156 after the host-side RIFF decode) ----
+ * sushi_hip_load_resample : data[pad + u] = nearest-neighbour decimation of the one-second chunks of the
+ *     downmixed frames (cv2.resize INTER_NEAREST, wav.py:125-137: sx = min(floor(x * scale), chunk - 1) in
+ *     float64), zeros where the reference never writes, and both pads filled with the nearest inner sample
+ *     (wav.py:140-141).  n_full chunks of `chunk` frames become nl_full samples each (scale_full =
+ *     1 / (nl_full / chunk)); a last partial chunk of `rest` frames becomes nl_rest samples.
+ * sushi_hip_load_histogram: 256-bin histogram (uint64) of key byte `shift/8` over the samples >= 0
+ *     (side 0; key = bit pattern) or <= 0 (side 1; key = bit pattern of -x) whose key & mask == prefix:
+ *     the building block of the exact radix select behind np.median(data[data >= 0]) (wav.py:145-146).
+ * sushi_hip_load_normalise: in place clip to [lo, hi], subtract lo, divide by range (wav.py:148-151);
+ *     if u8_dev != NULL also v * 255 + 0.5 truncated to uint8 (wav.py:153-156). */
+SUSHI_HIP_API int sushi_hip_load_resample(const float* raw_dev, int64_t n_raw, int32_t chunk, int32_t nl_full, double scale_full,
+                            int64_t n_full, int32_t rest, int32_t nl_rest, double scale_rest,
+                            int64_t pad, int64_t total, float* data_dev, void* hip_stream);
+SUSHI_HIP_API int sushi_hip_load_histogram(const float* data_dev, int64_t n, int side, uint32_t prefix, uint32_t mask, int shift,
+                             uint64_t* hist_dev, void* hip_stream);
+SUSHI_HIP_API int sushi_hip_load_normalise(float* data_dev, int64_t n, float lo, float hi, float range, uint8_t* u8_dev,
+                             void* hip_stream);
+
 /* Optional per-stage timing of sushi_hip_match_batch_fft with HIP events recorded on the launch
  * stream (bench.py's roofline figures).  Between _begin and _end every call records its stage
  * boundaries; _end waits for them and writes, per call, the milliseconds spent in each stage

@@ -82,6 +82,13 @@ def lib():
     L.sushi_hip_match_batch_fft.restype = ci
     L.sushi_hip_match_batch_fft.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, i64, dbl, ci, vp, vp, ci, dbl,
                                             vp, sz, vp, vp, vp, vp, vp]
+    u32, cf = ctypes.c_uint32, ctypes.c_float
+    L.sushi_hip_load_resample.restype = ci
+    L.sushi_hip_load_resample.argtypes = [vp, i64, i32, i32, dbl, i64, i32, i32, dbl, i64, i64, vp, vp]
+    L.sushi_hip_load_histogram.restype = ci
+    L.sushi_hip_load_histogram.argtypes = [vp, i64, ci, u32, u32, ci, vp, vp]
+    L.sushi_hip_load_normalise.restype = ci
+    L.sushi_hip_load_normalise.argtypes = [vp, i64, cf, cf, cf, vp, vp]
     L.sushi_hip_profile_begin.restype = ci
     L.sushi_hip_profile_end.restype = ci
     L.sushi_hip_profile_end.argtypes = [vp, ci, ctypes.POINTER(ci)]

@@ -3,6 +3,7 @@
 Two translation units, compiled separately (the MFMA kernel alone takes ~2 min) and linked:
   csrc/sushi_hip.hip  direct MFMA kernel, stream preparation, exact refinement   (-ffp-contract=off)
   csrc/sushi_fft.hip  overlap-save FFT path
+  csrc/sushi_load.hip WavStream load pipeline (decimate / pad / median clip / scale / quantise)  (-ffp-contract=off)
 """
 import math
 import os
@@ -22,6 +23,7 @@ COMMON_DEPS = [HEADER, os.path.join(CSRC, "sushi_common.hpp"), os.path.join(CSRC
 # a*b-c*d would round differently from the reference (the hot loop is MFMA builtins, unaffected).
 UNITS = [
     ("sushi_hip", ["-ffp-contract=off"], []),
+    ("sushi_load", ["-ffp-contract=off"], []),      # NumPy's float32 operation order, no fused multiply-add
     # -fno-slp-vectorize: the SLP pass packs the complex MACs into v_pk_fma_f32 and pays for it in
     # register shuffles (v_mov / accvgpr traffic); plain v_fma_f32 already issues at the f32 peak rate.
     ("sushi_fft", ["-fno-slp-vectorize"],

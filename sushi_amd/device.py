@@ -32,24 +32,36 @@ class DeviceStream(object):
     """HBM-resident, match-ready form of a 1-D sample row (uint8 or float32)."""
 
     def __init__(self, samples, device=None, keep_raw=False):
-        samples = np.ascontiguousarray(samples)
-        if samples.ndim == 2 and samples.shape[0] == 1:
-            samples = samples[0]
-        if samples.ndim != 1:
-            raise SushiError("DeviceStream expects a 1-D (or (1, N)) sample array")
-        if samples.dtype not in _DTYPE_CODE:
-            raise SushiError("Unknown sample type of WAV stream, must be uint8 or float32")
+        """`samples`: a host array (1-D or (1, N), uint8 / float32) -- uploaded -- or a 1-D torch tensor
+        of those dtypes that already lives on the GPU (used as is)."""
+        on_device = isinstance(samples, torch.Tensor)
+        if on_device:
+            if samples.dim() != 1 or not samples.is_cuda or not samples.is_contiguous():
+                raise SushiError("DeviceStream expects a contiguous 1-D CUDA tensor")
+            np_dtype = {torch.uint8: np.dtype(np.uint8), torch.float32: np.dtype(np.float32)}.get(samples.dtype)
+            if np_dtype is None:
+                raise SushiError("Unknown sample type of WAV stream, must be uint8 or float32")
+            device = samples.device
+        else:
+            samples = np.ascontiguousarray(samples)
+            if samples.ndim == 2 and samples.shape[0] == 1:
+                samples = samples[0]
+            if samples.ndim != 1:
+                raise SushiError("DeviceStream expects a 1-D (or (1, N)) sample array")
+            if samples.dtype not in _DTYPE_CODE:
+                raise SushiError("Unknown sample type of WAV stream, must be uint8 or float32")
+            np_dtype = samples.dtype
         if samples.shape[0] < 1:
             raise SushiError("empty sample array")
         self.device = _require_gpu(device)
-        self.dtype = samples.dtype
-        self.dtype_code = _DTYPE_CODE[samples.dtype]
+        self.dtype = np_dtype
+        self.dtype_code = _DTYPE_CODE[np_dtype]
         self.n = int(samples.shape[0])
         L = _native.lib()
         _native.check(L.sushi_hip_device_ok(), "device check")
         self.centre = float(L.sushi_hip_centre(self.dtype_code))
         with torch.cuda.device(self.device):
-            raw = torch.from_numpy(samples).to(self.device, non_blocking=False)
+            raw = samples if on_device else torch.from_numpy(samples).to(self.device, non_blocking=False)
             self.xc = torch.empty(self.n, dtype=torch.float32, device=self.device)
             self.s1 = torch.empty(self.n + 1, dtype=torch.float64, device=self.device)
             self.s2 = torch.empty(self.n + 1, dtype=torch.float64, device=self.device)

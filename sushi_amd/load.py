@@ -1,0 +1,101 @@
+"""WavStream's value pipeline on the GPU (reference wav.py:113-156 after the RIFF decode).
+
+Host: RIFF parse + channel downmix (``DownmixedWavFile``), the chunk bookkeeping of wav.py:113-137
+(how many samples each one-second chunk becomes) and the 256-bin bucket walks of the radix select.
+Device (libsushi_hip.so, csrc/sushi_load.hip): decimation + padding, the histograms behind the two
+medians, clip / scale / quantise.  The result is bit-identical to ``wav.WavStream._build_host`` and the
+normalised stream never crosses PCIe twice: the device copy is handed to ``DeviceStream`` as is.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _native
+from .common import SushiError
+
+
+def _py2_round(x):
+    """Python 2 round(): half away from zero (wav.py:127)."""
+    return math.floor(x + 0.5) if x >= 0 else -math.floor(-x + 0.5)
+
+
+def _select(L, data, n, side, rank, hist, stream):
+    """Key (uint32) of the element of ascending-key rank `rank` among the samples of one side."""
+    prefix, mask = 0, 0
+    for shift in (24, 16, 8, 0):
+        _native.check(L.sushi_hip_load_histogram(data.data_ptr(), n, side, prefix, mask, shift, hist.data_ptr(), stream),
+                      "sushi_hip_load_histogram")
+        h = hist.cpu().numpy()
+        c = np.cumsum(h)
+        b = int(np.searchsorted(c, rank, side="right"))
+        if b > 255:
+            raise SushiError("radix select: rank outside the population")
+        rank -= int(c[b - 1]) if b else 0
+        prefix |= b << shift
+        mask |= 0xFF << shift
+    return prefix
+
+
+def _median(L, data, n, side, hist, stream):
+    """np.median(data[data >= 0]) (side 0) / np.median(data[data <= 0]) (side 1) as a Python float."""
+    _native.check(L.sushi_hip_load_histogram(data.data_ptr(), n, side, 0, 0, 24, hist.data_ptr(), stream),
+                  "sushi_hip_load_histogram")
+    m = int(hist.cpu().numpy().sum())
+    if m == 0:
+        raise SushiError("stream has no samples on one side of zero")
+
+    def value(ascending_rank):
+        # side 1 holds keys of -x: ascending x is descending key
+        r = ascending_rank if side == 0 else m - 1 - ascending_rank
+        v = np.array([_select(L, data, n, side, r, hist, stream)], np.uint32).view(np.float32)[0]
+        return v if side == 0 else np.float32(-v)
+
+    if m % 2:
+        return float(value(m // 2))
+    lo, hi = value(m // 2 - 1), value(m // 2)
+    return float(np.float32(lo + hi) / np.float32(2.0))       # np.mean of two float32 values
+
+
+def build_on_device(samples, framerate, frames_count, sample_rate, sample_type, device=None, read_chunk_size=1,
+                    padding_seconds=10):
+    """-> (host data ndarray (1, L) of dtype uint8/float32, device tensor of the same row, sample_count, padding_size)"""
+    if sample_type not in ('float32', 'uint8'):
+        raise SushiError('Unknown sample type of WAV stream, must be uint8 or float32')
+    L = _native.lib()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    total_seconds = frames_count / float(framerate)
+    downsample_rate = sample_rate / float(framerate)
+    sample_count = math.ceil(total_seconds * sample_rate)
+    padding_size = 10 * framerate
+    total = int(padding_seconds * 2 * framerate + sample_count)
+    chunk = int(read_chunk_size * framerate)
+    n_raw = int(samples.shape[0])
+    n_full, rest = divmod(n_raw, chunk)
+    nl_full = int(_py2_round(chunk * downsample_rate))
+    nl_rest = int(_py2_round(rest * downsample_rate)) if rest else 0
+    if downsample_rate != 1 and (nl_full <= 0):
+        raise SushiError('sample rate too low for one-second chunks')
+    scale_full = 1.0 / (float(nl_full) / float(chunk)) if nl_full > 0 else 0.0
+    scale_rest = 1.0 / (float(nl_rest) / float(rest)) if nl_rest > 0 else 0.0
+    if total - 2 * padding_size < n_full * nl_full + nl_rest:
+        raise SushiError('decimated stream does not fit its buffer')         # np.copyto would raise in the reference
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream(dev).cuda_stream
+        raw = torch.from_numpy(np.ascontiguousarray(samples, dtype=np.float32)).to(dev)
+        data = torch.empty(total, dtype=torch.float32, device=dev)
+        _native.check(L.sushi_hip_load_resample(raw.data_ptr(), n_raw, chunk, nl_full, scale_full, n_full, rest, nl_rest,
+                                                scale_rest, padding_size, total, data.data_ptr(), st),
+                      "sushi_hip_load_resample")
+        hist = torch.empty(256, dtype=torch.int64, device=dev)
+        max_value = _median(L, data, total, 0, hist, st) * 3
+        min_value = _median(L, data, total, 1, hist, st) * 3
+        lo, hi, rng = np.float32(min_value), np.float32(max_value), np.float32(max_value - min_value)
+        u8 = torch.empty(total, dtype=torch.uint8, device=dev) if sample_type == 'uint8' else None
+        _native.check(L.sushi_hip_load_normalise(data.data_ptr(), total, ctypes.c_float(lo), ctypes.c_float(hi),
+                                                 ctypes.c_float(rng), u8.data_ptr() if u8 is not None else None, st),
+                      "sushi_hip_load_normalise")
+        row = u8 if u8 is not None else data
+        host = row.cpu().numpy().reshape(1, -1)
+    return host, row, sample_count, padding_size

@@ -4,8 +4,10 @@ Same constructor, attributes and methods as reference wav.py:104-188; ``find_sub
 the GPU (libsushi_hip.so) instead of ``cv2.matchTemplate`` + ``argmin`` (wav.py:185-186).
 Extensions: ``WavStream.from_samples`` (in-memory PCM), ``find_substreams`` (batched).
 
-The load pipeline (wav.py:108-162) is host code here too (NumPy, whole-file instead of the
-reference's one-second Python loop); it is not on the hot path.
+The load pipeline (wav.py:108-162): RIFF decode and downmix on the host; decimation, padding, the
+two medians, clip / scale / quantise on the GPU when one is present (sushi_amd/load.py,
+csrc/sushi_load.hip) and otherwise in NumPy (``_build_host``, bit-identical; it is what the CPU
+tests compare with the oracle).  ``SUSHI_HIP_LOAD=host`` forces the NumPy pipeline.
 """
 import logging
 import math
@@ -124,6 +126,12 @@ class DownmixedWavFile(object):
 _live_streams = weakref.WeakSet()
 
 
+def torch_device(device):
+    import torch
+    d = torch.device(device)
+    return torch.device("cuda", torch.cuda.current_device()) if d.type == "cuda" and d.index is None else d
+
+
 def _locate(pattern):
     """If `pattern` is a view into a live WavStream's host data (what get_substream and np.split
     of it return, sushi.py:417,445), return (stream, offset, length); else None."""
@@ -175,8 +183,28 @@ class WavStream(object):
         _live_streams.add(self)
         return self
 
-    # wav.py:113-156 (value pipeline), whole-stream instead of chunk-by-chunk
     def _build(self, samples, framerate, frames_count, sample_rate, sample_type):
+        """wav.py:113-156: on the GPU if there is one (the normalised row then stays in HBM for the
+        matching), else in NumPy."""
+        self._dev_row = None
+        use_gpu = os.environ.get("SUSHI_HIP_LOAD", "auto") != "host"
+        if use_gpu:
+            try:
+                import torch
+                use_gpu = torch.cuda.is_available()
+            except ImportError:
+                use_gpu = False
+        if not use_gpu:
+            return self._build_host(samples, framerate, frames_count, sample_rate, sample_type)
+        from .load import build_on_device
+        self.data, self._dev_row, self.sample_count, self.padding_size = build_on_device(
+            samples, framerate, frames_count, sample_rate, sample_type,
+            read_chunk_size=self.READ_CHUNK_SIZE, padding_seconds=self.PADDING_SECONDS)
+        self.sample_rate = sample_rate
+
+    # wav.py:113-156 (value pipeline) in NumPy, whole-stream instead of chunk-by-chunk
+    def _build_host(self, samples, framerate, frames_count, sample_rate, sample_type):
+        self._dev_row = None
         total_seconds = frames_count / float(framerate)
         downsample_rate = sample_rate / float(framerate)
         self.sample_count = math.ceil(total_seconds * sample_rate)
@@ -242,7 +270,12 @@ class WavStream(object):
         """The HBM mirror of self.data (created on first use)."""
         if self._dev is None:
             from .device import DeviceStream
-            self._dev = DeviceStream(self.data[0], device=self._device)
+            row = getattr(self, "_dev_row", None)
+            if row is not None and (self._device is None or str(row.device) == str(torch_device(self._device))):
+                self._dev = DeviceStream(row)           # already in HBM (GPU load pipeline): no H2D
+            else:
+                self._dev = DeviceStream(self.data[0], device=self._device)
+            self._dev_row = None
         return self._dev
 
     def _window(self, pattern_len, window_center, window_size):
