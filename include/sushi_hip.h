@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SUSHI_HIP_ABI_VERSION 2
+#define SUSHI_HIP_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define SUSHI_HIP_API __attribute__((visibility("default")))
@@ -86,13 +86,16 @@ SUSHI_HIP_API int sushi_hip_variant_tile_positions(int variant);
 
 /* Stream preparation.  raw_dev: n samples of `dtype` (the row WavStream.data[0]).
  * Outputs: xc_dev[n] float32 = sample - centre (centre = 0.5 for float32 data in [0,1],
- * 128 for uint8), s1_dev[n+1] / s2_dev[n+1] float64 exclusive prefix sums of xc and xc^2.
- * xc_dev must be 16-byte aligned.  ws_dev: scratch of sushi_hip_prepare_workspace_bytes(n). */
-SUSHI_HIP_API size_t sushi_hip_prepare_workspace_bytes(int64_t n);
+ * 128 for uint8); s1_dev[n+1] / s2_dev[n+1] float64 exclusive prefix sums of xc and xc^2 (the CV_64F
+ * integral cv2 builds per call); and the same sums in the cheap form the FFT path's scoring reads:
+ * rel_dev[2*(n+1)] float32 pairs and base_dev = float64[2][nb+1], nb = ceil(n / B), B = sushi_hip_fft_hop():
+ *     s1[e] = base[0][e / B] + rel[2e],  s2[e] = base[1][e / B] + rel[2e+1]      (e = 0 .. n)
+ * xc_dev must be 16-byte aligned; base_bytes >= sushi_hip_prepare_base_bytes(n). */
+SUSHI_HIP_API size_t sushi_hip_prepare_base_bytes(int64_t n);
 SUSHI_HIP_API double sushi_hip_centre(int dtype);
 SUSHI_HIP_API int sushi_hip_prepare_stream(const void* raw_dev, int dtype, int64_t n,
                              float* xc_dev, double* s1_dev, double* s2_dev,
-                             void* ws_dev, size_t ws_bytes, void* hip_stream);
+                             float* rel_dev, double* base_dev, size_t base_bytes, void* hip_stream);
 
 /* Batched template match + arg-minimum.
  *   dst_* : prepared search stream (the WavStream find_substream is called on), dst_len samples
@@ -133,17 +136,20 @@ SUSHI_HIP_API int sushi_hip_prepare_spectra(const float* xc_dev, int64_t n, void
                                             void* hip_stream);
 
 /* Same results as sushi_hip_match_batch.  Additional arguments:
+ *   dst_rel_dev / dst_base_dev : the relative prefix sums and block bases of the dst stream
  *   dst_spec_dev      : sushi_hip_prepare_spectra output for the dst stream
  *   searches_host     : the same n_search descriptors in host memory (read during the call only);
  *                       first_tile must be laid out for variant sushi_hip_variant_count()-1,
  *                       first_pair / first_seg as running sums of sushi_hip_fft_layout()
- *   delta             : score margin (> 2x the FFT error; 2e-5 is ample for WavStream data)
+ *   delta             : score margin (> 2x the error of the f32 FFT scores; 2e-5 is ample for WavStream data.
+ *                       Windows whose centred energy is so large against their norm that the f32 error could
+ *                       approach delta/4 are detected and the search is finished by the direct kernel)
  *   ws_dev / ws_bytes : scratch, >= sushi_hip_fft_workspace_bytes(pairs, segments, 1) of the largest search
  *   keys_ws_dev       : uint64[2 * n_search] scratch
  *   flags_dev         : int32[2 * n_search + 2] scratch; on completion flags[k] = 1 if search k had too
  *                       many near-ties and was finished by the direct kernel, flags[n_search] = how many */
 SUSHI_HIP_API int sushi_hip_match_batch_fft(const float* dst_xc_dev, const double* dst_s1_dev, const double* dst_s2_dev, int64_t dst_len,
-                              const void* dst_spec_dev,
+                              const float* dst_rel_dev, const double* dst_base_dev, const void* dst_spec_dev,
                               const float* src_xc_dev, const double* src_s1_dev, const double* src_s2_dev, int64_t src_len,
                               double centre, int method,
                               const SushiHipSearch* searches_dev, const SushiHipSearch* searches_host,

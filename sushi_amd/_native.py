@@ -18,7 +18,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sushi_hip.h")
 U8, F32 = 0, 1
 SQDIFF_NORMED = 0
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NSTAGES = 5
 STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish")
 
@@ -59,12 +59,12 @@ def lib():
     L.sushi_hip_variant_count.restype = ci
     L.sushi_hip_variant_tile_positions.restype = ci
     L.sushi_hip_variant_tile_positions.argtypes = [ci]
-    L.sushi_hip_prepare_workspace_bytes.restype = sz
-    L.sushi_hip_prepare_workspace_bytes.argtypes = [i64]
+    L.sushi_hip_prepare_base_bytes.restype = sz
+    L.sushi_hip_prepare_base_bytes.argtypes = [i64]
     L.sushi_hip_centre.restype = dbl
     L.sushi_hip_centre.argtypes = [ci]
     L.sushi_hip_prepare_stream.restype = ci
-    L.sushi_hip_prepare_stream.argtypes = [vp, ci, i64, vp, vp, vp, vp, sz, vp]
+    L.sushi_hip_prepare_stream.argtypes = [vp, ci, i64, vp, vp, vp, vp, vp, sz, vp]
     L.sushi_hip_match_batch.restype = ci
     L.sushi_hip_match_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp, i64, dbl, ci, vp, ci, ci, ci, vp, vp, vp, vp]
     i32 = ctypes.c_int32
@@ -80,7 +80,7 @@ def lib():
     L.sushi_hip_prepare_spectra.restype = ci
     L.sushi_hip_prepare_spectra.argtypes = [vp, i64, vp, sz, vp]
     L.sushi_hip_match_batch_fft.restype = ci
-    L.sushi_hip_match_batch_fft.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, i64, dbl, ci, vp, vp, ci, dbl,
+    L.sushi_hip_match_batch_fft.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, dbl, ci, vp, vp, ci, dbl,
                                             vp, sz, vp, vp, vp, vp, vp]
     u32, cf = ctypes.c_uint32, ctypes.c_float
     L.sushi_hip_load_resample.restype = ci

@@ -302,8 +302,9 @@ void refine_kernel(RefineArgs a) {
     for (int e = tid; e < n_ent; e += 256) {
         const unsigned long long key = c[e];
         if (key != NO_KEY && key_score(key) <= thr) {
-            if (key_pos(key) == 0xffffffffu) {
-                ovf = 1;                                   // that pair had more near-minimum positions than slots
+            if (key_pos(key) >= 0xfffffffeu) {
+                ovf = 1;                                   // that pair had more near-minimum positions than slots, or
+                                                           // declared its f32 scores untrustworthy (ifft_kernel)
             } else {
                 const int slot = atomicAdd(&cnt, 1);
                 if (slot < RCAP) list[slot] = key; else ovf = 1;
@@ -359,6 +360,7 @@ void refine_kernel(RefineArgs a) {
 constexpr int PB_THREADS = 256;
 constexpr int PB_PER_THREAD = 16;
 constexpr int PB = PB_THREADS * PB_PER_THREAD;   // 4096 samples per block
+static_assert(PB == FFT_HOP, "the relative prefix sums are per FFT block");
 
 template <typename T> __device__ __forceinline__ float centred(T x);
 template <> __device__ __forceinline__ float centred<float>(float x) { return x - 0.5f; }
@@ -393,7 +395,8 @@ void centre_blocksum_kernel(const T* __restrict__ raw, int64_t n, float* __restr
     }
 }
 
-// single workgroup: in-place exclusive scan of the per-block totals
+// single workgroup: in-place exclusive scan of the per-block totals; entry [nb] receives the grand total,
+// so that bs[b] = prefix sum at sample min(b * PB, n) for b = 0 .. nb (the "block bases")
 __global__ __launch_bounds__(1024)
 void scan_blocksums_kernel(double* __restrict__ bs1, double* __restrict__ bs2, int nb) {
     __shared__ double w1[16], w2[16];
@@ -417,11 +420,15 @@ void scan_blocksums_kernel(double* __restrict__ bs1, double* __restrict__ bs2, i
         if (tid == 1023) { carry[0] = o1 + e1 + v1; carry[1] = o2 + e2 + v2; }
         __syncthreads();
     }
+    if (tid == 0) { bs1[nb] = carry[0]; bs2[nb] = carry[1]; }
 }
 
+// prefix sums s1/s2 (float64, absolute) and rel (float32 pairs, relative to the base of the sample's
+// PB-block): s[e] = base[e / PB] + rel[e] for e = 0 .. n
 __global__ __launch_bounds__(PB_THREADS)
 void final_scan_kernel(const float* __restrict__ xc, int64_t n, const double* __restrict__ bs1,
-                       const double* __restrict__ bs2, double* __restrict__ s1, double* __restrict__ s2) {
+                       const double* __restrict__ bs2, double* __restrict__ s1, double* __restrict__ s2,
+                       float2* __restrict__ rel) {
     __shared__ double w1[PB_THREADS / 64], w2[PB_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * PB + (int64_t)tid * PB_PER_THREAD;  // 16 consecutive samples
@@ -439,18 +446,22 @@ void final_scan_kernel(const float* __restrict__ xc, int64_t n, const double* __
     double e2 = wave_excl_scan(l2, &t2);
     if (lane == 0) { w1[wv] = t1; w2[wv] = t2; }
     __syncthreads();
-    double o1 = bs1[blockIdx.x], o2 = bs2[blockIdx.x];
-    for (int w = 0; w < wv; ++w) { o1 += w1[w]; o2 += w2[w]; }
-    double r1 = o1 + e1, r2 = o2 + e2;           // exclusive prefix at sample `base`
-    if (blockIdx.x == 0 && tid == 0) { s1[0] = 0.0; s2[0] = 0.0; }
+    for (int w = 0; w < wv; ++w) { e1 += w1[w]; e2 += w2[w]; }        // prefix inside the block, before sample `base`
+    const double o1 = bs1[blockIdx.x], o2 = bs2[blockIdx.x];          // block base
+    if (blockIdx.x == 0 && tid == 0) {
+        s1[0] = 0.0; s2[0] = 0.0;
+        if (n % PB == 0) rel[n] = make_float2(0.f, 0.f);              // sample n opens a block of its own: base[n / PB] = total
+    }
 #pragma unroll
     for (int k = 0; k < PB_PER_THREAD; ++k) {
         const int64_t e = base + k;
         if (e < n) {
-            r1 += (double)v[k];
-            r2 += (double)v[k] * (double)v[k];
-            s1[e + 1] = r1;
-            s2[e + 1] = r2;
+            rel[e] = make_float2((float)e1, (float)e2);
+            e1 += (double)v[k];
+            e2 += (double)v[k] * (double)v[k];
+            s1[e + 1] = o1 + e1;
+            s2[e + 1] = o2 + e2;
+            if (e + 1 == n && (n % PB) != 0) rel[n] = make_float2((float)e1, (float)e2);
         }
     }
 }
@@ -539,25 +550,26 @@ int sushi_hip_variant_tile_positions(int variant) {
 
 double sushi_hip_centre(int dtype) { return dtype == SUSHI_HIP_U8 ? 128.0 : 0.5; }
 
-size_t sushi_hip_prepare_workspace_bytes(int64_t n) {
+size_t sushi_hip_prepare_base_bytes(int64_t n) {
     if (n < 0) return 0;
     const int64_t nb = (n + PB - 1) / PB;
-    return (size_t)(2 * (nb > 0 ? nb : 1)) * sizeof(double);
+    return (size_t)(2 * (nb + 1)) * sizeof(double);
 }
 
 int sushi_hip_prepare_stream(const void* raw_dev, int dtype, int64_t n, float* xc_dev, double* s1_dev,
-                             double* s2_dev, void* ws_dev, size_t ws_bytes, void* hip_stream) {
-    if (!raw_dev || !xc_dev || !s1_dev || !s2_dev || !ws_dev || n <= 0) return SUSHI_HIP_EINVAL;
+                             double* s2_dev, float* rel_dev, double* base_dev, size_t base_bytes, void* hip_stream) {
+    if (!raw_dev || !xc_dev || !s1_dev || !s2_dev || !rel_dev || !base_dev || n <= 0) return SUSHI_HIP_EINVAL;
     if (dtype != SUSHI_HIP_U8 && dtype != SUSHI_HIP_F32) return SUSHI_HIP_EINVAL;
-    if (((uintptr_t)xc_dev & 15) || ((uintptr_t)s1_dev & 7) || ((uintptr_t)s2_dev & 7) || ((uintptr_t)ws_dev & 7))
+    if (((uintptr_t)xc_dev & 15) || ((uintptr_t)s1_dev & 7) || ((uintptr_t)s2_dev & 7) || ((uintptr_t)base_dev & 7) ||
+        ((uintptr_t)rel_dev & 7))
         return SUSHI_HIP_EALIGN;
-    if (ws_bytes < sushi_hip_prepare_workspace_bytes(n)) return SUSHI_HIP_ENOSPACE;
+    if (base_bytes < sushi_hip_prepare_base_bytes(n)) return SUSHI_HIP_ENOSPACE;
     const int64_t nb64 = (n + PB - 1) / PB;
-    if (nb64 > 0x7fffffff) return SUSHI_HIP_EINVAL;
+    if (nb64 > 0x7ffffffe) return SUSHI_HIP_EINVAL;
     const int nb = (int)nb64;
     hipStream_t st = (hipStream_t)hip_stream;
-    double* bs1 = (double*)ws_dev;
-    double* bs2 = bs1 + nb;
+    double* bs1 = base_dev;
+    double* bs2 = bs1 + (nb + 1);
     if (dtype == SUSHI_HIP_F32)
         hipLaunchKernelGGL(centre_blocksum_kernel<float>, dim3(nb), dim3(PB_THREADS), 0, st,
                            (const float*)raw_dev, n, xc_dev, bs1, bs2);
@@ -568,7 +580,7 @@ int sushi_hip_prepare_stream(const void* raw_dev, int dtype, int64_t n, float* x
     hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1024), 0, st, bs1, bs2, nb);
     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
     hipLaunchKernelGGL(final_scan_kernel, dim3(nb), dim3(PB_THREADS), 0, st, (const float*)xc_dev, n,
-                       (const double*)bs1, (const double*)bs2, s1_dev, s2_dev);
+                       (const double*)bs1, (const double*)bs2, s1_dev, s2_dev, (float2*)rel_dev);
     return launch_ok();
 }
 

@@ -65,13 +65,16 @@ class DeviceStream(object):
             self.xc = torch.empty(self.n, dtype=torch.float32, device=self.device)
             self.s1 = torch.empty(self.n + 1, dtype=torch.float64, device=self.device)
             self.s2 = torch.empty(self.n + 1, dtype=torch.float64, device=self.device)
-            ws_bytes = int(L.sushi_hip_prepare_workspace_bytes(self.n))
-            ws = torch.empty(max(ws_bytes // 8, 2), dtype=torch.float64, device=self.device)
+            # the same prefix sums as float32 pairs relative to per-block float64 bases (FFT path scoring)
+            self.rel = torch.empty(2 * (self.n + 1), dtype=torch.float32, device=self.device)
+            base_bytes = int(L.sushi_hip_prepare_base_bytes(self.n))
+            self.base = torch.empty(base_bytes // 8, dtype=torch.float64, device=self.device)
             rc = L.sushi_hip_prepare_stream(raw.data_ptr(), self.dtype_code, self.n,
                                             self.xc.data_ptr(), self.s1.data_ptr(), self.s2.data_ptr(),
-                                            ws.data_ptr(), ws.numel() * 8, _raw_stream(self.device))
+                                            self.rel.data_ptr(), self.base.data_ptr(), base_bytes,
+                                            _raw_stream(self.device))
             _native.check(rc, "sushi_hip_prepare_stream")
-            torch.cuda.current_stream(self.device).synchronize()   # ws/raw may be freed now
+            torch.cuda.current_stream(self.device).synchronize()   # raw may be freed now
         self.raw = raw if keep_raw else None
         self._spec = None
 
@@ -89,7 +92,7 @@ class DeviceStream(object):
         return self._spec
 
     def nbytes(self):
-        return self.xc.numel() * 4 + (self.s1.numel() + self.s2.numel()) * 8 + \
+        return self.xc.numel() * 4 + (self.s1.numel() + self.s2.numel() + self.base.numel()) * 8 + self.rel.numel() * 4 + \
             (0 if self._spec is None else self._spec.numel() * 4)
 
 
@@ -208,7 +211,7 @@ class SearchBatch(object):
         st = _raw_stream(dst.device) if hip_stream is None else hip_stream
         if self.path == "fft":
             rc = L.sushi_hip_match_batch_fft(dst.xc.data_ptr(), dst.s1.data_ptr(), dst.s2.data_ptr(), dst.n,
-                                             self.spec.data_ptr(),
+                                             dst.rel.data_ptr(), dst.base.data_ptr(), self.spec.data_ptr(),
                                              src.xc.data_ptr(), src.s1.data_ptr(), src.s2.data_ptr(), src.n,
                                              dst.centre, _native.SQDIFF_NORMED,
                                              self.desc.data_ptr(), self.host_desc.ctypes.data, self.n, self.delta,

@@ -88,6 +88,17 @@ def test_prepare_stream(dtype, n):
     else:
         np.testing.assert_allclose(g1, s1, rtol=0, atol=1e-9 * max(1.0, np.abs(s1).max()))
         np.testing.assert_allclose(g2, s2, rtol=1e-11, atol=1e-9)   # np.cumsum itself rounds sequentially
+    # the relative form: s[e] = base[e // 4096] + rel[e] to float32 accuracy of the in-block part
+    nb = (n + 4095) // 4096
+    base = d.base.cpu().numpy().reshape(2, nb + 1)
+    rel = d.rel.cpu().numpy().reshape(n + 1, 2)
+    e = np.arange(n + 1)
+    for col, g in ((0, g1), (1, g2)):
+        rebuilt = base[col][e // 4096] + rel[:, col].astype(np.float64)
+        tol = 4096 * (128.0 ** 2 if dtype == np.uint8 else 0.25) * 2.0 ** -23
+        assert np.abs(rebuilt - g).max() <= tol
+    assert (base[:, 0] == 0).all()
+    assert abs(base[0, nb] - g1[n]) <= 1e-12 * max(1.0, abs(g1[n])) and abs(base[1, nb] - g2[n]) <= 1e-12 * max(1.0, abs(g2[n]))
 
 
 @pytest.mark.parametrize("variant", PATHS)
@@ -409,3 +420,25 @@ def test_config5_sizes_24khz_four_hour_streams(oracle):
     """BASELINE configs[4] sizes: 4-h 24 kHz streams (346 M samples, 5.5 GB of block spectra), +-120 s
     (P = 5,760,001), templates up to 5 s = 120,000 samples = 30 segments (two multiply-accumulate chunks)."""
     _planted_config(14400, 24000, 120, 8, -17.25 + 40.0, seed=41, n_oracle=1, oracle=oracle, min_len=3.0, max_len=5.0)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_fft_ill_conditioned_streams_fall_back(oracle, dtype):
+    """Streams that sit far from the centring constant (uint8 samples 0..6, float32 samples ~0.19): the
+    centred energies dwarf the norms the score divides by and f32 FFT scores cannot be trusted to rank.
+    ifft_kernel detects it (conditioning limit), the search goes to the direct kernel, results stay exact.
+    (float32 samples much below 0.125 would additionally lose bits in `x - 0.5` itself -- DESIGN.md 4.)"""
+    rng = np.random.default_rng(23)
+    n = 60000
+    if dtype == np.uint8:
+        dst = rng.integers(0, 7, n, dtype=np.uint8)
+    else:
+        dst = (np.float32(0.18) + rng.random(n, dtype=np.float32) * np.float32(0.02)).astype(np.float32)
+    src = dst[30000:30000 + 5000].copy()
+    src[::3] = dst[100:100 + 5000][::3]                     # a noisy copy: minimum well above 0
+    (idx, score), b = _run_batch(dst, src, [0, 0], [5000, 2500], [1000, 20000], [50001, 20001], "fft", want_batch=True)
+    assert b.fallback_count() == 2
+    for k, (m, w, p) in enumerate([(5000, 1000, 50001), (2500, 20000, 20001)]):
+        res = oracle.match_template(dst[w:w + p + m - 1], src[:m])[0]
+        (_check_u8 if dtype == np.uint8 else _check_f32)(res, idx[k], score[k])
+    assert idx[0] == 29000 and idx[1] == 10000

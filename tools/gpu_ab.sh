@@ -1,18 +1,9 @@
 set -x
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -q -x --durations=5 > gpurun_out/pytest_gpu.log 2>&1; tail -12 gpurun_out/pytest_gpu.log
-python - <<'PY'
-import time, numpy as np, torch
-from sushi_amd import synth
-from sushi_amd.wav import WavStream
-import os
-pcm = synth.make_dst_pcm(2700, 12000, seed=1)
-for mode in ("auto", "host", "auto"):
-    os.environ["SUSHI_HIP_LOAD"] = mode
-    for st in ("float32", "uint8"):
-        torch.cuda.synchronize(); t = time.time()
-        w = WavStream.from_samples(pcm, 12000, sample_rate=12000, sample_type=st)
-        d = w.device_stream(); torch.cuda.synchronize()
-        print(mode, st, "load+prepare s:", round(time.time() - t, 4))
-PY
+timeout 1500 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1; tail -5 gpurun_out/pytest_gpu.log
+B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -o fetch -- $B > gpurun_out/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/prof_write -o write -- $B > gpurun_out/write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d gpurun_out/prof_sq1 -o sq1 -- $B > gpurun_out/sq1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU --output-format csv -d gpurun_out/prof_sq2 -o sq2 -- $B > gpurun_out/sq2.log 2>&1
