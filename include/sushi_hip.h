@@ -131,6 +131,13 @@ SUSHI_HIP_API int sushi_hip_fft_layout(int64_t win_start, int32_t n_pos, int32_t
  * more workspace = fewer, larger launches; the minimum is what the largest single search needs). */
 SUSHI_HIP_API size_t sushi_hip_fft_workspace_bytes(int64_t n_pairs, int64_t n_seg, int64_t n_search);
 
+/* Optional L2-friendly schedule of the inverse-transform workgroups: order_host[total pairs of the batch]
+ * receives, per sub-batch (as cut for a workspace of ws_bytes), a permutation of the sub-batch's pairs in
+ * which pairs scoring the same region of the destination stream run back to back on one XCD.  Host-side,
+ * computed once per batch; upload it and pass it as pair_order_dev (or pass NULL: workgroup = pair). */
+SUSHI_HIP_API int sushi_hip_fft_pair_order(const SushiHipSearch* searches_host, int n_search, size_t ws_bytes,
+                             int32_t* order_host, int64_t order_len);
+
 /* xc_dev: centred stream from sushi_hip_prepare_stream (16-byte aligned); spec_dev: output. */
 SUSHI_HIP_API int sushi_hip_prepare_spectra(const float* xc_dev, int64_t n, void* spec_dev, size_t spec_bytes,
                                             void* hip_stream);
@@ -146,6 +153,7 @@ SUSHI_HIP_API int sushi_hip_prepare_spectra(const float* xc_dev, int64_t n, void
  *                       approach delta/4 are detected and the search is finished by the direct kernel)
  *   ws_dev / ws_bytes : scratch, >= sushi_hip_fft_workspace_bytes(pairs, segments, 1) of the largest search
  *   keys_ws_dev       : uint64[2 * n_search] scratch
+ *   pair_order_dev    : int32[total pairs] from sushi_hip_fft_pair_order for the SAME ws_bytes, or NULL
  *   flags_dev         : int32[2 * n_search + 2] scratch; on completion flags[k] = 1 if search k had too
  *                       many near-ties and was finished by the direct kernel, flags[n_search] = how many */
 SUSHI_HIP_API int sushi_hip_match_batch_fft(const float* dst_xc_dev, const double* dst_s1_dev, const double* dst_s2_dev, int64_t dst_len,
@@ -155,7 +163,7 @@ SUSHI_HIP_API int sushi_hip_match_batch_fft(const float* dst_xc_dev, const doubl
                               const SushiHipSearch* searches_dev, const SushiHipSearch* searches_host,
                               int n_search, double delta,
                               void* ws_dev, size_t ws_bytes,
-                              uint64_t* keys_ws_dev, int32_t* flags_dev,
+                              uint64_t* keys_ws_dev, int32_t* flags_dev, const int32_t* pair_order_dev,
                               int32_t* out_idx_dev, float* out_score_dev, void* hip_stream);
 
 /* ---- WavStream.__init__ value pipeline on the GPU (wav.py:113-156 after the host-side RIFF decode) ----

@@ -81,7 +81,9 @@ def lib():
     L.sushi_hip_prepare_spectra.argtypes = [vp, i64, vp, sz, vp]
     L.sushi_hip_match_batch_fft.restype = ci
     L.sushi_hip_match_batch_fft.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, dbl, ci, vp, vp, ci, dbl,
-                                            vp, sz, vp, vp, vp, vp, vp]
+                                            vp, sz, vp, vp, vp, vp, vp, vp]
+    L.sushi_hip_fft_pair_order.restype = ci
+    L.sushi_hip_fft_pair_order.argtypes = [vp, ci, sz, vp, i64]
     u32, cf = ctypes.c_uint32, ctypes.c_float
     L.sushi_hip_load_resample.restype = ci
     L.sushi_hip_load_resample.argtypes = [vp, i64, i32, i32, dbl, i64, i32, i32, dbl, i64, i64, vp, vp]

@@ -5,14 +5,17 @@
 // OpenCV's crossCorr() (templmatch.cpp, behind cv2.matchTemplate at reference wav.py:185) is the same
 // block-DFT scheme on the CPU.
 //
-// Stockham autosort, radix plan 16 x 8 x 8 x 8.  A pass of radix R with NS = product of the earlier
+// Stockham autosort, radix plan 8 x 8 x 8 x 16.  A pass of radix R with NS = product of the earlier
 // radices processes butterflies j = 0 .. N/R-1:
 //     inputs   x[j + t*N/R] * w^(t*k),   k = j mod NS,  w = exp(DIR*2*pi*i / (NS*R)),  t = 0..R-1
 //     outputs  y[(j - k)*R + k + t*NS]   = R-point DFT of the inputs
-// Pass 1 has NS = 1 (no twiddles) and takes its inputs from registers (the caller loads them from
-// HBM); the last pass leaves its outputs in registers: thread `tid` ends with X[tid + 512*m], m = 0..15.
-// Between passes the data goes through one LDS buffer, padded by one element per 16 so that the
-// transposing stores of every pass are bank-conflict free (ds_write_b64: 16-lane groups, 32 banks).
+// Pass 1 (NS = 1, no twiddles) takes its inputs from registers, and a thread owns the two ADJACENT
+// butterflies j = 2*tid, 2*tid + 1: its inputs x[2*tid + b + 1024*t] are 16-byte pairs, so that the
+// caller can fill them with dwordx4 loads (8-byte global loads reach only ~0.6 of the HBM rate on
+// gfx950).  In the other passes a thread owns j = tid (+ 512).  The last pass leaves its outputs in
+// registers: thread `tid` ends with X[tid + 512*r], r = 0..15.  Between passes the data goes through
+// one LDS buffer, padded by one element per 16 (pad(e) = e + e/16) so that the transposing stores are
+// (nearly) bank-conflict free; all pad() arithmetic is folded into per-thread bases plus immediates.
 //
 // Everything here is written against explicit (tid, lds) arguments so that tests/host_fft_check.cpp
 // can run the same code on the CPU, one "thread" at a time, with the barriers replaced by loops.
@@ -80,35 +83,41 @@ struct Dft<1, DIR> {
 };
 
 // Base twiddles of the three twiddled passes for this thread, w^1 = exp(DIR*2*pi*i*k/(NS*R)) with
-// k = j mod NS: the two butterflies of a thread (j = tid, tid + 512) share k in passes 2 and 3.
+// k = j mod NS: the two butterflies of a thread (j = tid, tid + 512) share k in passes 2 and 3, and
+// pass 4 (radix 16) has one butterfly per thread.
 // tw[n] = exp(-2*pi*i*n/N), n = 0..N-1 (the forward table; the inverse conjugates it).
 // Loaded once, before the first barrier, so that no table load sits between two passes.
-struct Twiddles { cpx p2, p3, p4a, p4b; };
+struct Twiddles { cpx p2, p3, p4; };
 
 template <int DIR>
 SUSHI_HD Twiddles load_twiddles(int tid, const cpx* __restrict__ tw) {
     Twiddles t;
-    t.p2 = tw[(tid & 15) * (N / 128)];
-    t.p3 = tw[(tid & 127) * (N / 1024)];
-    t.p4a = tw[tid];
-    t.p4b = tw[tid + NT];
-    if (DIR > 0) { t.p2 = cconj(t.p2); t.p3 = cconj(t.p3); t.p4a = cconj(t.p4a); t.p4b = cconj(t.p4b); }
+    t.p2 = tw[(tid & 7) * (N / 64)];
+    t.p3 = tw[(tid & 63) * (N / 512)];
+    t.p4 = tw[tid];
+    if (DIR > 0) { t.p2 = cconj(t.p2); t.p3 = cconj(t.p3); t.p4 = cconj(t.p4); }
     return t;
 }
 
+// which butterfly: pass 1 pairs adjacent ones in a thread, the others stride by the workgroup size
+template <bool FIRST>
+SUSHI_HD int butterfly(int tid, int b) { return FIRST ? 2 * tid + b : tid + b * NT; }
+
 // One pass, register side: twiddle (unless NS == 1) and butterfly the PER points of this thread.
-// v[b*R + t] holds input t of butterfly j = tid + b*NT; w1[b] is that butterfly's base twiddle.
+// v[b*R + t] holds input t of the thread's butterfly b; w1 is the base twiddle (shared by both).
 template <int R, int NS, int DIR>
-SUSHI_HD void pass_compute(cpx* v, const cpx* w1) {
+SUSHI_HD void pass_compute(cpx* v, const cpx w1) {
     constexpr int NB = PER / R;
+    cpx w[R];
+    if (NS > 1) {
+        w[1] = w1;
+#pragma unroll
+        for (int t = 2; t < R; ++t) w[t] = (t & 1) ? cmul(w[t - 1], w[1]) : cmul(w[t / 2], w[t / 2]);
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         cpx* x = v + b * R;
         if (NS > 1) {
-            cpx w[R];
-            w[1] = w1[b];
-#pragma unroll
-            for (int t = 2; t < R; ++t) w[t] = (t & 1) ? cmul(w[t - 1], w[1]) : cmul(w[t / 2], w[t / 2]);
 #pragma unroll
             for (int t = 1; t < R; ++t) x[t] = cmul(x[t], w[t]);
         }
@@ -116,21 +125,24 @@ SUSHI_HD void pass_compute(cpx* v, const cpx* w1) {
     }
 }
 
-// store the outputs of a pass into the (padded) LDS buffer.  pad(base + t*NS) is written as
-// pad(base) + t*(NS + NS/16) (exact when NS is a multiple of 16; for NS = 1, base = 16 j and
-// pad(16 j + t) = 17 j + t) so that every access is one address register plus an immediate offset.
-template <int R, int NS>
+// store the outputs of a pass into the (padded) LDS buffer: element base + t*NS with base = (j-k)*R + k.
+//   NS = 1 : base = 8 j, and a thread's two butterflies (j = 2 tid, 2 tid + 1) fill elements 16 tid .. 16 tid + 15:
+//            pad(16 tid + u) = 17 tid + u
+//   NS = 8 : base = 64 (j >> 3) + k, pad(base + 8 t) = 68 (j >> 3) + k + 8 t + (t >> 1)
+//   NS = 64: base + 64 t, a multiple-of-16 step: pad(base + 64 t) = pad(base) + 68 t
+template <int R, int NS, bool FIRST>
 SUSHI_HD void pass_store(const cpx* v, int tid, cpx* lds) {
     constexpr int NB = PER / R;
-    static_assert(NS == 1 || NS % 16 == 0, "padding arithmetic assumes NS = 1 or a multiple of 16");
+    static_assert(NS == 1 || NS == 8 || NS % 16 == 0, "padding arithmetic");
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const int j = tid + b * NT;
+        const int j = butterfly<FIRST>(tid, b);
         const int k = j & (NS - 1);
         const int base = (j - k) * R + k;
-        cpx* out = lds + (NS == 1 ? base + j : pad(base));
+        cpx* out = lds + (NS == 1 ? base + (base >> 4) : (NS == 8 ? 68 * (j >> 3) + k : pad(base)));
 #pragma unroll
-        for (int t = 0; t < R; ++t) out[NS == 1 ? t : t * (NS + NS / 16)] = v[b * R + t];
+        for (int t = 0; t < R; ++t)
+            out[NS == 1 ? t : (NS == 8 ? 8 * t + (t >> 1) : t * (NS + NS / 16))] = v[b * R + t];
     }
 }
 
@@ -142,7 +154,7 @@ SUSHI_HD void pass_load(cpx* v, int tid, const cpx* lds) {
     static_assert(STRIDE % 16 == 0, "padding arithmetic assumes N/R is a multiple of 16");
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const int j = tid + b * NT;
+        const int j = butterfly<false>(tid, b);
         const cpx* in = lds + pad(j);
 #pragma unroll
         for (int t = 0; t < R; ++t) v[b * R + t] = in[t * (STRIDE + STRIDE / 16)];
@@ -150,39 +162,37 @@ SUSHI_HD void pass_load(cpx* v, int tid, const cpx* lds) {
 }
 
 // Index maps of the whole transform (what the caller needs to load / interpret registers):
-//   input : v[t]        = x[tid + 512*t]                  t = 0..15   (pass 1 is radix 16, one butterfly per thread)
-//   output: v[b*8 + t]  = X[tid + 512*(b + 2*t)]          b = 0..1, t = 0..7
-SUSHI_HD int in_index(int tid, int r) { return tid + NT * r; }
-SUSHI_HD int out_index(int tid, int r) { return tid + NT * ((r >> 3) + 2 * (r & 7)); }
+//   input : v[b*8 + t] = x[2*tid + b + 1024*t]     b = 0..1, t = 0..7   (adjacent pairs: 16-byte loads)
+//   output: v[r]       = X[tid + 512*r]            r = 0..15
+SUSHI_HD int in_index(int tid, int r) { return 2 * tid + (r >> 3) + (N / 8) * (r & 7); }
+SUSHI_HD int out_index(int tid, int r) { return tid + NT * r; }
 
 #ifdef __HIPCC__
 #define SUSHI_FFT_BARRIER() __syncthreads()
-// Full transform of the 16 points in v (in_index layout) -> v (out_index layout).
-// `lds` must hold LDS_ELEMS elements; contents are dead after the call's last barrier... the buffer may be
-// reused by the caller after one further __syncthreads().
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
-// `before_last_pass` runs after the third pass's stores and before the last pass: a place to issue
-// independent global loads whose latency the last pass then covers.
+// Full transform of the 16 points in v (in_index layout) -> v (out_index layout).
+// `lds` must hold LDS_ELEMS elements; its contents are dead once the call returns and it may be
+// reused after one further __syncthreads().  `before_last_pass` runs after the third pass's stores and
+// before the last pass: a place to issue independent global loads whose latency the last pass covers.
 template <int DIR, class Hook = NoHook>
 __device__ __forceinline__ void fft8192(cpx* v, int tid, cpx* lds, const Twiddles tw, Hook before_last_pass = Hook()) {
-    const cpx w2[2] = {tw.p2, tw.p2}, w3[2] = {tw.p3, tw.p3}, w4[2] = {tw.p4a, tw.p4b};
-    pass_compute<16, 1, DIR>(v, nullptr);
-    pass_store<16, 1>(v, tid, lds);
+    pass_compute<8, 1, DIR>(v, cpx{1.f, 0.f});
+    pass_store<8, 1, true>(v, tid, lds);
     SUSHI_FFT_BARRIER();
     pass_load<8>(v, tid, lds);
-    pass_compute<8, 16, DIR>(v, w2);
+    pass_compute<8, 8, DIR>(v, tw.p2);
     SUSHI_FFT_BARRIER();
-    pass_store<8, 16>(v, tid, lds);
+    pass_store<8, 8, false>(v, tid, lds);
     SUSHI_FFT_BARRIER();
     pass_load<8>(v, tid, lds);
-    pass_compute<8, 128, DIR>(v, w3);
+    pass_compute<8, 64, DIR>(v, tw.p3);
     SUSHI_FFT_BARRIER();
-    pass_store<8, 128>(v, tid, lds);
+    pass_store<8, 64, false>(v, tid, lds);
     before_last_pass();
     SUSHI_FFT_BARRIER();
-    pass_load<8>(v, tid, lds);
-    pass_compute<8, 1024, DIR>(v, w4);
+    pass_load<16>(v, tid, lds);
+    pass_compute<16, 512, DIR>(v, tw.p4);
 }
 #endif
 

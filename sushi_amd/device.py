@@ -189,6 +189,10 @@ class SearchBatch(object):
             self.ws_bytes = max(need_one, min(need_all, int(workspace_bytes)))
             self.delta = float(delta)
             self.fft_pairs, self.fft_segs = int(pairs.sum()), int(segs.sum())
+            # L2-friendly schedule of the inverse-transform workgroups (host side, once per batch)
+            self.host_order = np.empty(self.fft_pairs, np.int32)
+            _native.check(L.sushi_hip_fft_pair_order(desc.ctypes.data, n, self.ws_bytes, self.host_order.ctypes.data,
+                                                     self.fft_pairs), "sushi_hip_fft_pair_order")
         self.host_desc = desc
         # algorithmic work of this batch: 2*P*M flop, 4*(P+M-1)+4*M+8 bytes per search
         self.flops = float((2.0 * n_pos.astype(np.float64) * tmpl_len.astype(np.float64)).sum())
@@ -203,6 +207,7 @@ class SearchBatch(object):
                 self.flags = torch.zeros(2 * n + 2, dtype=torch.int32, device=dev)
                 self.ws = torch.empty((self.ws_bytes + 255) // 256 * 64, dtype=torch.float32, device=dev)
                 self.spec = dst.spectra()
+                self.order = torch.from_numpy(self.host_order).to(dev)
 
     def run(self, hip_stream=None):
         """One pass of the hot path over this batch (asynchronous)."""
@@ -216,7 +221,7 @@ class SearchBatch(object):
                                              dst.centre, _native.SQDIFF_NORMED,
                                              self.desc.data_ptr(), self.host_desc.ctypes.data, self.n, self.delta,
                                              self.ws.data_ptr(), self.ws_bytes,
-                                             self.keys.data_ptr(), self.flags.data_ptr(),
+                                             self.keys.data_ptr(), self.flags.data_ptr(), self.order.data_ptr(),
                                              self.out_idx.data_ptr(), self.out_score.data_ptr(), st)
             _native.check(rc, "sushi_hip_match_batch_fft")
             return self.out_idx, self.out_score

@@ -47,14 +47,13 @@ static double run(const std::vector<cpx>& tw, unsigned seed) {
     for (int tid = 0; tid < NT; ++tid)
         for (int q = 0; q < PER; ++q) regs[(size_t)tid * PER + q] = x[in_index(tid, q)];
 #define ALL(stmt) for (int tid = 0; tid < NT; ++tid) { cpx* v = &regs[(size_t)tid * PER]; \
-        const Twiddles t = load_twiddles<DIR>(tid, tw.data()); \
-        const cpx w2[2] = {t.p2, t.p2}, w3[2] = {t.p3, t.p3}, w4[2] = {t.p4a, t.p4b}; (void)w2; (void)w3; (void)w4; stmt; }
-    ALL((pass_compute<16, 1, DIR>(v, nullptr), pass_store<16, 1>(v, tid, lds.data())))
-    ALL((pass_load<8>(v, tid, lds.data()), pass_compute<8, 16, DIR>(v, w2)))
-    ALL((pass_store<8, 16>(v, tid, lds.data())))
-    ALL((pass_load<8>(v, tid, lds.data()), pass_compute<8, 128, DIR>(v, w3)))
-    ALL((pass_store<8, 128>(v, tid, lds.data())))
-    ALL((pass_load<8>(v, tid, lds.data()), pass_compute<8, 1024, DIR>(v, w4)))
+        const Twiddles t = load_twiddles<DIR>(tid, tw.data()); (void)t; stmt; }
+    ALL((pass_compute<8, 1, DIR>(v, cpx{1.f, 0.f}), pass_store<8, 1, true>(v, tid, lds.data())))
+    ALL((pass_load<8>(v, tid, lds.data()), pass_compute<8, 8, DIR>(v, t.p2)))
+    ALL((pass_store<8, 8, false>(v, tid, lds.data())))
+    ALL((pass_load<8>(v, tid, lds.data()), pass_compute<8, 64, DIR>(v, t.p3)))
+    ALL((pass_store<8, 64, false>(v, tid, lds.data())))
+    ALL((pass_load<16>(v, tid, lds.data()), pass_compute<16, 512, DIR>(v, t.p4)))
     double err2 = 0, ref2 = 0;
     for (int tid = 0; tid < NT; ++tid)
         for (int q = 0; q < PER; ++q) {

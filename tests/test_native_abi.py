@@ -57,7 +57,27 @@ def test_host_only_entry_points():
     assert L.sushi_hip_fft_workspace_bytes(176555, 9379, 1000) > L.sushi_hip_fft_workspace_bytes(176555, 9379, 1)
     assert L.sushi_hip_prepare_spectra(None, 10, None, 0, None) == -1
     assert L.sushi_hip_match_batch_fft(None, None, None, 0, None, None, None, None, None, None, 0, 0.5, 0, None, None,
-                                       0, 2e-5, None, 0, None, None, None, None, None) == -1
+                                       0, 2e-5, None, 0, None, None, None, None, None, None) == -1
+    # the inverse-transform schedule is a permutation of each sub-batch's pairs
+    win = np.array([100000, 140000, 190000, 300000], np.int64)       # equal shapes: with the smallest workspace
+    npos = np.array([240001, 240001, 240001, 240001], np.int64)       # no two searches share a sub-batch
+    mlen = np.array([36000, 36000, 36000, 36000], np.int64)
+    vp_, vs_ = _native.fft_layout(win, npos, mlen)
+    desc = np.zeros(4, _native.SEARCH_DTYPE)
+    desc["win_start"], desc["n_pos"], desc["tmpl_len"] = win, npos, mlen
+    desc["first_pair"][1:] = np.cumsum(vp_[:-1]); desc["first_seg"][1:] = np.cumsum(vs_[:-1])
+    total = int(vp_.sum())
+    for ws in (1 << 40, int(L.sushi_hip_fft_workspace_bytes(int(vp_.max()), int(vs_.max()), 1))):
+        order = np.full(total, -1, np.int32)
+        assert L.sushi_hip_fft_pair_order(desc.ctypes.data, 4, ws, order.ctypes.data, total) == 0
+        if ws > (1 << 39):
+            assert sorted(order.tolist()) == list(range(total))          # one sub-batch
+        else:                                                             # one search per sub-batch
+            lo = 0
+            for k in range(4):
+                assert sorted(order[lo:lo + int(vp_[k])].tolist()) == list(range(int(vp_[k])))
+                lo += int(vp_[k])
+    assert L.sushi_hip_fft_pair_order(desc.ctypes.data, 4, 1 << 40, order.ctypes.data, total + 1) == -1
     n = C.c_int(-1)
     assert L.sushi_hip_profile_end(None, 0, C.byref(n)) == -1
 
