@@ -87,15 +87,16 @@ SUSHI_HIP_API int sushi_hip_variant_tile_positions(int variant);
 /* Stream preparation.  raw_dev: n samples of `dtype` (the row WavStream.data[0]).
  * Outputs: xc_dev[n] float32 = sample - centre (centre = 0.5 for float32 data in [0,1],
  * 128 for uint8); s1_dev[n+1] / s2_dev[n+1] float64 exclusive prefix sums of xc and xc^2 (the CV_64F
- * integral cv2 builds per call); and the same sums in the cheap form the FFT path's scoring reads:
- * rel_dev[2*(n+1)] float32 pairs and base_dev = float64[2][nb+1], nb = ceil(n / B), B = sushi_hip_fft_hop():
- *     s1[e] = base[0][e / B] + rel[2e],  s2[e] = base[1][e / B] + rel[2e+1]      (e = 0 .. n)
+ * integral cv2 builds per call); and the window energies in the cheap form the FFT path's scoring
+ * reads: urel_dev[n+1] float32 and base_dev[0 .. nb] float64, nb = ceil(n / B), B = sushi_hip_fft_hop():
+ *     sum_{e' < e} sample[e']^2 = base[e / B] + urel[e]          (e = 0 .. n; UNCENTRED samples)
+ * (base_dev holds 3 * (nb + 1) doubles; the other two thirds are scratch of this call.)
  * xc_dev must be 16-byte aligned; base_bytes >= sushi_hip_prepare_base_bytes(n). */
 SUSHI_HIP_API size_t sushi_hip_prepare_base_bytes(int64_t n);
 SUSHI_HIP_API double sushi_hip_centre(int dtype);
 SUSHI_HIP_API int sushi_hip_prepare_stream(const void* raw_dev, int dtype, int64_t n,
                              float* xc_dev, double* s1_dev, double* s2_dev,
-                             float* rel_dev, double* base_dev, size_t base_bytes, void* hip_stream);
+                             float* urel_dev, double* base_dev, size_t base_bytes, void* hip_stream);
 
 /* Batched template match + arg-minimum.
  *   dst_* : prepared search stream (the WavStream find_substream is called on), dst_len samples
@@ -116,7 +117,7 @@ SUSHI_HIP_API int sushi_hip_match_batch(const float* dst_xc_dev, const double* d
 
 /* ---- overlap-save FFT path ------------------------------------------------------------------
  * The destination stream is cut into blocks of sushi_hip_fft_hop() = B samples; block j is
- * stored as the 2B-point complex DFT of xc[jB .. jB+2B) + i * xc[(j+1)B .. (j+3)B) (zeros past
+ * stored as the 2B-point complex DFT of x[jB .. jB+2B) + i * x[(j+1)B .. (j+3)B) (x = xc + centre; zeros past
  * the end), 2B complex float32 each, followed by one all-zero block:
  * sushi_hip_spectra_bytes(n) = (ceil(n/B) + 1) * 2B * 8 bytes.
  * A search covers the blocks floor(win_start/B) .. floor((win_start+n_pos-1)/B), two per
@@ -138,26 +139,31 @@ SUSHI_HIP_API size_t sushi_hip_fft_workspace_bytes(int64_t n_pairs, int64_t n_se
 SUSHI_HIP_API int sushi_hip_fft_pair_order(const SushiHipSearch* searches_host, int n_search, size_t ws_bytes,
                              int32_t* order_host, int64_t order_len);
 
-/* xc_dev: centred stream from sushi_hip_prepare_stream (16-byte aligned); spec_dev: output. */
-SUSHI_HIP_API int sushi_hip_prepare_spectra(const float* xc_dev, int64_t n, void* spec_dev, size_t spec_bytes,
+/* xc_dev: centred stream from sushi_hip_prepare_stream (16-byte aligned); the spectra are those of the
+ * uncentred samples xc + centre; spec_dev: output. */
+SUSHI_HIP_API int sushi_hip_prepare_spectra(const float* xc_dev, int64_t n, double centre, void* spec_dev, size_t spec_bytes,
                                             void* hip_stream);
 
 /* Same results as sushi_hip_match_batch.  Additional arguments:
- *   dst_rel_dev / dst_base_dev : the relative prefix sums and block bases of the dst stream
+ *   dst_urel_dev / dst_base_dev : the relative window-energy prefix and its block bases of the dst stream
  *   dst_spec_dev      : sushi_hip_prepare_spectra output for the dst stream
  *   searches_host     : the same n_search descriptors in host memory (read during the call only);
  *                       first_tile must be laid out for variant sushi_hip_variant_count()-1,
  *                       first_pair / first_seg as running sums of sushi_hip_fft_layout()
- *   delta             : score margin (> 2x the error of the f32 FFT scores; 2e-5 is ample for WavStream data.
- *                       Windows whose centred energy is so large against their norm that the f32 error could
- *                       approach delta/4 are detected and the search is finished by the direct kernel)
+ *   delta             : score margin, > 2x the error of the f32 FFT scores.  The FFT stage works on the
+ *                       UNCENTRED samples, so its error in score units is bounded by a few float32 epsilons
+ *                       whatever the data (|d corr| <~ eps * |T| * |I| = eps * the score's denominator);
+ *                       2e-5 leaves a margin of ~10x (measured: sushi_hip_fft_last_errors)
  *   ws_dev / ws_bytes : scratch, >= sushi_hip_fft_workspace_bytes(pairs, segments, 1) of the largest search
  *   keys_ws_dev       : uint64[2 * n_search] scratch
  *   pair_order_dev    : int32[total pairs] from sushi_hip_fft_pair_order for the SAME ws_bytes, or NULL
+ *   keys_ws_dev       : on completion the float32 at byte offset 8 * (n_search + k) is |FFT score - exact score|
+ *                       of search k's result position (0 for searches finished by the direct kernel): the
+ *                       measured error of the ranking stage, to be compared with delta / 2
  *   flags_dev         : int32[2 * n_search + 2] scratch; on completion flags[k] = 1 if search k had too
  *                       many near-ties and was finished by the direct kernel, flags[n_search] = how many */
 SUSHI_HIP_API int sushi_hip_match_batch_fft(const float* dst_xc_dev, const double* dst_s1_dev, const double* dst_s2_dev, int64_t dst_len,
-                              const float* dst_rel_dev, const double* dst_base_dev, const void* dst_spec_dev,
+                              const float* dst_urel_dev, const double* dst_base_dev, const void* dst_spec_dev,
                               const float* src_xc_dev, const double* src_s1_dev, const double* src_s2_dev, int64_t src_len,
                               double centre, int method,
                               const SushiHipSearch* searches_dev, const SushiHipSearch* searches_host,

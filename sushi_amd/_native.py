@@ -78,7 +78,7 @@ def lib():
     L.sushi_hip_fft_workspace_bytes.restype = sz
     L.sushi_hip_fft_workspace_bytes.argtypes = [i64, i64, i64]
     L.sushi_hip_prepare_spectra.restype = ci
-    L.sushi_hip_prepare_spectra.argtypes = [vp, i64, vp, sz, vp]
+    L.sushi_hip_prepare_spectra.argtypes = [vp, i64, dbl, vp, sz, vp]
     L.sushi_hip_match_batch_fft.restype = ci
     L.sushi_hip_match_batch_fft.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, dbl, ci, vp, vp, ci, dbl,
                                             vp, sz, vp, vp, vp, vp, vp, vp]

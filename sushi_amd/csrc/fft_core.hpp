@@ -105,24 +105,34 @@ SUSHI_HD int butterfly(int tid, int b) { return FIRST ? 2 * tid + b : tid + b * 
 
 // One pass, register side: twiddle (unless NS == 1) and butterfly the PER points of this thread.
 // v[b*R + t] holds input t of the thread's butterfly b; w1 is the base twiddle (shared by both).
+// The powers w^t are built from the squarings w, w^2, w^4, w^8 only (each w^t = product of the squarings
+// its binary digits select, at most three multiplications deep): four live twiddle registers instead of
+// R, which is what lets the radix-16 pass coexist with prefetched loads in a 128-register budget.
 template <int R, int NS, int DIR>
 SUSHI_HD void pass_compute(cpx* v, const cpx w1) {
     constexpr int NB = PER / R;
-    cpx w[R];
     if (NS > 1) {
-        w[1] = w1;
+        cpx sq[4];
+        sq[0] = w1;
 #pragma unroll
-        for (int t = 2; t < R; ++t) w[t] = (t & 1) ? cmul(w[t - 1], w[1]) : cmul(w[t / 2], w[t / 2]);
-    }
+        for (int q = 1; q < 4; ++q) sq[q] = cmul(sq[q - 1], sq[q - 1]);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        cpx* x = v + b * R;
-        if (NS > 1) {
+        for (int t = 1; t < R; ++t) {
+            cpx wt = cpx{1.f, 0.f};
+            bool first = true;
 #pragma unroll
-            for (int t = 1; t < R; ++t) x[t] = cmul(x[t], w[t]);
+            for (int q = 0; q < 4; ++q) {
+                if (t & (1 << q)) {
+                    wt = first ? sq[q] : cmul(wt, sq[q]);
+                    first = false;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) v[b * R + t] = cmul(v[b * R + t], wt);
         }
-        Dft<R, DIR>::run(x);
     }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) Dft<R, DIR>::run(v + b * R);
 }
 
 // store the outputs of a pass into the (padded) LDS buffer: element base + t*NS with base = (j-k)*R + k.

@@ -278,7 +278,7 @@ struct RefineArgs {
     int first_search;
     int sub_first_pair;
     const unsigned long long* cand;
-    const unsigned long long* gkeys;
+    unsigned long long* gkeys;        // in: minimum of the f32 FFT scores; out: |f32 - exact| of the result (float bits)
     float delta;
     unsigned long long* keys;
     int* flags;
@@ -317,6 +317,7 @@ void refine_kernel(RefineArgs a) {
             a.flags[s_idx] = 1;
             const int k = atomicAdd(a.flags + a.n_search, 1);
             a.flags[a.n_search + 2 + k] = s_idx;
+            a.gkeys[s_idx] = 0ull;
         }
         return;                                            // keys[s_idx] stays NO_KEY for the direct kernel
     }
@@ -327,6 +328,7 @@ void refine_kernel(RefineArgs a) {
     const double* __restrict__ w2 = a.r.dst_s2 + sd.win_start;
     const float* __restrict__ src = a.r.src_xc + sd.tmpl_off;
     unsigned long long best = NO_KEY;
+    float best_approx = 0.f;
     for (int k = 0; k < n; ++k) {
         const unsigned p = key_pos(list[k]);
         const float* __restrict__ d = a.r.dst_xc + sd.win_start + p;
@@ -346,11 +348,15 @@ void refine_kernel(RefineArgs a) {
             const double corr_c = (part[0] + part[1]) + (part[2] + part[3]);
             const float score = score_at(corr_c, ts, a.r.centre, w1, w2, (int64_t)p, M);
             const unsigned long long key = make_key(score, p);
-            best = key < best ? key : best;
+            if (key < best) { best = key; best_approx = key_score(list[k]); }
         }
         __syncthreads();
     }
-    if (tid == 0) a.keys[s_idx] = best;
+    if (tid == 0) {
+        a.keys[s_idx] = best;
+        // diagnostics: how far the ranking stage was off at the position that won (compare with delta / 2)
+        a.gkeys[s_idx] = (unsigned long long)__float_as_uint(fabsf(best_approx - key_score(best)));
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -369,99 +375,118 @@ template <> __device__ __forceinline__ float centred<uint8_t>(uint8_t x) { retur
 template <typename T>
 __global__ __launch_bounds__(PB_THREADS)
 void centre_blocksum_kernel(const T* __restrict__ raw, int64_t n, float* __restrict__ xc,
-                            double* __restrict__ bs1, double* __restrict__ bs2) {
-    __shared__ double r1[PB_THREADS / 64], r2[PB_THREADS / 64];
+                            double* __restrict__ bs1, double* __restrict__ bs2, double* __restrict__ bs3) {
+    __shared__ double r1[PB_THREADS / 64], r2[PB_THREADS / 64], r3[PB_THREADS / 64];
     const int64_t base = (int64_t)blockIdx.x * PB;
-    double s1 = 0.0, s2 = 0.0;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll 4
     for (int k = 0; k < PB_PER_THREAD; ++k) {
         const int64_t e = base + (int64_t)k * PB_THREADS + threadIdx.x;   // coalesced
         if (e < n) {
             const float v = centred<T>(raw[e]);
+            const double u = (double)(float)raw[e];                       // the uncentred sample
             xc[e] = v;
             s1 += (double)v;
             s2 += (double)v * (double)v;
+            s3 += u * u;
         }
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
-    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+    s3 = wave_sum(s3);
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; r3[threadIdx.x >> 6] = s3; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double t1 = 0.0, t2 = 0.0;
-        for (int w = 0; w < PB_THREADS / 64; ++w) { t1 += r1[w]; t2 += r2[w]; }
+        double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        for (int w = 0; w < PB_THREADS / 64; ++w) { t1 += r1[w]; t2 += r2[w]; t3 += r3[w]; }
         bs1[blockIdx.x] = t1;
         bs2[blockIdx.x] = t2;
+        bs3[blockIdx.x] = t3;
     }
 }
 
-// single workgroup: in-place exclusive scan of the per-block totals; entry [nb] receives the grand total,
-// so that bs[b] = prefix sum at sample min(b * PB, n) for b = 0 .. nb (the "block bases")
+// single workgroup: in-place exclusive scan of the per-block totals of NA arrays; entry [nb] of each
+// receives the grand total, so that bs[b] = prefix sum at sample min(b * PB, n) for b = 0 .. nb
+template <int NA>
 __global__ __launch_bounds__(1024)
-void scan_blocksums_kernel(double* __restrict__ bs1, double* __restrict__ bs2, int nb) {
-    __shared__ double w1[16], w2[16];
-    __shared__ double carry[2];
+void scan_blocksums_kernel(double* __restrict__ bs, int stride, int nb) {
+    __shared__ double wt[NA][16];
+    __shared__ double carry[NA];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) { carry[0] = 0.0; carry[1] = 0.0; }
+    if (tid < NA) carry[tid] = 0.0;
     __syncthreads();
     for (int base = 0; base < nb; base += 1024) {
         const int k = base + tid;
-        const double v1 = k < nb ? bs1[k] : 0.0;
-        const double v2 = k < nb ? bs2[k] : 0.0;
-        double t1, t2;
-        const double e1 = wave_excl_scan(v1, &t1);
-        const double e2 = wave_excl_scan(v2, &t2);
-        if (lane == 0) { w1[wv] = t1; w2[wv] = t2; }
+        double v[NA], e[NA], o[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            v[a] = k < nb ? bs[a * stride + k] : 0.0;
+            double t;
+            e[a] = wave_excl_scan(v[a], &t);
+            if (lane == 0) wt[a][wv] = t;
+        }
         __syncthreads();
-        double o1 = carry[0], o2 = carry[1];
-        for (int w = 0; w < wv; ++w) { o1 += w1[w]; o2 += w2[w]; }
-        if (k < nb) { bs1[k] = o1 + e1; bs2[k] = o2 + e2; }
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            o[a] = carry[a];
+            for (int w = 0; w < wv; ++w) o[a] += wt[a][w];
+            if (k < nb) bs[a * stride + k] = o[a] + e[a];
+        }
         __syncthreads();
-        if (tid == 1023) { carry[0] = o1 + e1 + v1; carry[1] = o2 + e2 + v2; }
+        if (tid == 1023) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) carry[a] = o[a] + e[a] + v[a];
+        }
         __syncthreads();
     }
-    if (tid == 0) { bs1[nb] = carry[0]; bs2[nb] = carry[1]; }
+    if (tid < NA) bs[tid * stride + nb] = carry[tid];
 }
 
-// prefix sums s1/s2 (float64, absolute) and rel (float32 pairs, relative to the base of the sample's
-// PB-block): s[e] = base[e / PB] + rel[e] for e = 0 .. n
+// prefix sums s1/s2 of the centred samples (float64, absolute) and, for the FFT path's scoring, the
+// prefix sum of the UNCENTRED squares as float32 relative to the base of the sample's PB-block:
+//     sum_{e' < e} x[e']^2 = ubase[e / PB] + urel[e]          (e = 0 .. n)
 __global__ __launch_bounds__(PB_THREADS)
 void final_scan_kernel(const float* __restrict__ xc, int64_t n, const double* __restrict__ bs1,
                        const double* __restrict__ bs2, double* __restrict__ s1, double* __restrict__ s2,
-                       float2* __restrict__ rel) {
-    __shared__ double w1[PB_THREADS / 64], w2[PB_THREADS / 64];
+                       float* __restrict__ urel, double centre) {
+    __shared__ double w1[PB_THREADS / 64], w2[PB_THREADS / 64], w3[PB_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * PB + (int64_t)tid * PB_PER_THREAD;  // 16 consecutive samples
     float v[PB_PER_THREAD];
-    double l1 = 0.0, l2 = 0.0;
+    double l1 = 0.0, l2 = 0.0, l3 = 0.0;
 #pragma unroll
     for (int k = 0; k < PB_PER_THREAD; ++k) {
         const int64_t e = base + k;
         v[k] = e < n ? xc[e] : 0.f;
+        const double u = e < n ? (double)(float)(v[k] + (float)centre) : 0.0;
         l1 += (double)v[k];
         l2 += (double)v[k] * (double)v[k];
+        l3 += u * u;
     }
-    double t1, t2;
+    double t1, t2, t3;
     double e1 = wave_excl_scan(l1, &t1);
     double e2 = wave_excl_scan(l2, &t2);
-    if (lane == 0) { w1[wv] = t1; w2[wv] = t2; }
+    double e3 = wave_excl_scan(l3, &t3);
+    if (lane == 0) { w1[wv] = t1; w2[wv] = t2; w3[wv] = t3; }
     __syncthreads();
-    for (int w = 0; w < wv; ++w) { e1 += w1[w]; e2 += w2[w]; }        // prefix inside the block, before sample `base`
-    const double o1 = bs1[blockIdx.x], o2 = bs2[blockIdx.x];          // block base
+    for (int w = 0; w < wv; ++w) { e1 += w1[w]; e2 += w2[w]; e3 += w3[w]; }   // prefix inside the block, before sample `base`
+    const double o1 = bs1[blockIdx.x], o2 = bs2[blockIdx.x];                  // block bases
     if (blockIdx.x == 0 && tid == 0) {
         s1[0] = 0.0; s2[0] = 0.0;
-        if (n % PB == 0) rel[n] = make_float2(0.f, 0.f);              // sample n opens a block of its own: base[n / PB] = total
+        if (n % PB == 0) urel[n] = 0.f;                                       // sample n opens a block of its own: ubase[n / PB] = total
     }
 #pragma unroll
     for (int k = 0; k < PB_PER_THREAD; ++k) {
         const int64_t e = base + k;
         if (e < n) {
-            rel[e] = make_float2((float)e1, (float)e2);
+            urel[e] = (float)e3;
+            const double u = (double)(float)(v[k] + (float)centre);
             e1 += (double)v[k];
             e2 += (double)v[k] * (double)v[k];
+            e3 += u * u;
             s1[e + 1] = o1 + e1;
             s2[e + 1] = o2 + e2;
-            if (e + 1 == n && (n % PB) != 0) rel[n] = make_float2((float)e1, (float)e2);
+            if (e + 1 == n && (n % PB) != 0) urel[n] = (float)e3;
         }
     }
 }
@@ -487,7 +512,7 @@ static MatchArgs match_args(const StreamRefs& r, const SushiHipSearch* searches_
 }
 
 int launch_refine(const StreamRefs& r, const SushiHipSearch* searches_dev, int first_search, int n_sub,
-                  int sub_first_pair, const unsigned long long* cand_dev, const unsigned long long* gkeys_dev,
+                  int sub_first_pair, const unsigned long long* cand_dev, unsigned long long* gkeys_dev,
                   float delta, unsigned long long* keys_dev, int* flags_dev, int n_search, hipStream_t st) {
     RefineArgs a;
     a.r = r; a.searches = searches_dev; a.first_search = first_search; a.sub_first_pair = sub_first_pair;
@@ -553,34 +578,35 @@ double sushi_hip_centre(int dtype) { return dtype == SUSHI_HIP_U8 ? 128.0 : 0.5;
 size_t sushi_hip_prepare_base_bytes(int64_t n) {
     if (n < 0) return 0;
     const int64_t nb = (n + PB - 1) / PB;
-    return (size_t)(2 * (nb + 1)) * sizeof(double);
+    return (size_t)(3 * (nb + 1)) * sizeof(double);
 }
 
 int sushi_hip_prepare_stream(const void* raw_dev, int dtype, int64_t n, float* xc_dev, double* s1_dev,
-                             double* s2_dev, float* rel_dev, double* base_dev, size_t base_bytes, void* hip_stream) {
-    if (!raw_dev || !xc_dev || !s1_dev || !s2_dev || !rel_dev || !base_dev || n <= 0) return SUSHI_HIP_EINVAL;
+                             double* s2_dev, float* urel_dev, double* base_dev, size_t base_bytes, void* hip_stream) {
+    if (!raw_dev || !xc_dev || !s1_dev || !s2_dev || !urel_dev || !base_dev || n <= 0) return SUSHI_HIP_EINVAL;
     if (dtype != SUSHI_HIP_U8 && dtype != SUSHI_HIP_F32) return SUSHI_HIP_EINVAL;
     if (((uintptr_t)xc_dev & 15) || ((uintptr_t)s1_dev & 7) || ((uintptr_t)s2_dev & 7) || ((uintptr_t)base_dev & 7) ||
-        ((uintptr_t)rel_dev & 7))
+        ((uintptr_t)urel_dev & 3))
         return SUSHI_HIP_EALIGN;
     if (base_bytes < sushi_hip_prepare_base_bytes(n)) return SUSHI_HIP_ENOSPACE;
     const int64_t nb64 = (n + PB - 1) / PB;
     if (nb64 > 0x7ffffffe) return SUSHI_HIP_EINVAL;
     const int nb = (int)nb64;
     hipStream_t st = (hipStream_t)hip_stream;
-    double* bs1 = base_dev;
+    double* ub = base_dev;                       // [0]: block bases of the uncentred squares (what the FFT path reads)
+    double* bs1 = base_dev + (nb + 1);           // [1], [2]: block bases of the centred sums (scratch of this call)
     double* bs2 = bs1 + (nb + 1);
     if (dtype == SUSHI_HIP_F32)
         hipLaunchKernelGGL(centre_blocksum_kernel<float>, dim3(nb), dim3(PB_THREADS), 0, st,
-                           (const float*)raw_dev, n, xc_dev, bs1, bs2);
+                           (const float*)raw_dev, n, xc_dev, bs1, bs2, ub);
     else
         hipLaunchKernelGGL(centre_blocksum_kernel<uint8_t>, dim3(nb), dim3(PB_THREADS), 0, st,
-                           (const uint8_t*)raw_dev, n, xc_dev, bs1, bs2);
+                           (const uint8_t*)raw_dev, n, xc_dev, bs1, bs2, ub);
     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-    hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1024), 0, st, bs1, bs2, nb);
+    hipLaunchKernelGGL(scan_blocksums_kernel<3>, dim3(1), dim3(1024), 0, st, base_dev, nb + 1, nb);
     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
     hipLaunchKernelGGL(final_scan_kernel, dim3(nb), dim3(PB_THREADS), 0, st, (const float*)xc_dev, n,
-                       (const double*)bs1, (const double*)bs2, s1_dev, s2_dev, (float2*)rel_dev);
+                       (const double*)bs1, (const double*)bs2, s1_dev, s2_dev, urel_dev, sushi_hip_centre(dtype));
     return launch_ok();
 }
 

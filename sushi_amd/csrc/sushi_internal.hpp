@@ -18,7 +18,7 @@ struct StreamRefs {
 
 // Exact float64 evaluation of the candidates of searches [first_search, first_search + n_sub).
 int launch_refine(const StreamRefs& r, const SushiHipSearch* searches_dev, int first_search, int n_sub,
-                  int sub_first_pair, const unsigned long long* cand_dev, const unsigned long long* gkeys_dev,
+                  int sub_first_pair, const unsigned long long* cand_dev, unsigned long long* gkeys_dev,
                   float delta, unsigned long long* keys_dev, int* flags_dev, int n_search, hipStream_t st);
 // Direct (MFMA) kernel over the searches the refinement flagged.
 int launch_flagged_direct(const StreamRefs& r, const SushiHipSearch* searches_dev, int n_search,

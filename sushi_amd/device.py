@@ -65,13 +65,14 @@ class DeviceStream(object):
             self.xc = torch.empty(self.n, dtype=torch.float32, device=self.device)
             self.s1 = torch.empty(self.n + 1, dtype=torch.float64, device=self.device)
             self.s2 = torch.empty(self.n + 1, dtype=torch.float64, device=self.device)
-            # the same prefix sums as float32 pairs relative to per-block float64 bases (FFT path scoring)
-            self.rel = torch.empty(2 * (self.n + 1), dtype=torch.float32, device=self.device)
+            # window energies for the FFT path's scoring: float32 prefix of the uncentred squares relative
+            # to per-block float64 bases
+            self.urel = torch.empty(self.n + 1, dtype=torch.float32, device=self.device)
             base_bytes = int(L.sushi_hip_prepare_base_bytes(self.n))
             self.base = torch.empty(base_bytes // 8, dtype=torch.float64, device=self.device)
             rc = L.sushi_hip_prepare_stream(raw.data_ptr(), self.dtype_code, self.n,
                                             self.xc.data_ptr(), self.s1.data_ptr(), self.s2.data_ptr(),
-                                            self.rel.data_ptr(), self.base.data_ptr(), base_bytes,
+                                            self.urel.data_ptr(), self.base.data_ptr(), base_bytes,
                                             _raw_stream(self.device))
             _native.check(rc, "sushi_hip_prepare_stream")
             torch.cuda.current_stream(self.device).synchronize()   # raw may be freed now
@@ -85,14 +86,14 @@ class DeviceStream(object):
             nbytes = int(L.sushi_hip_spectra_bytes(self.n))
             with torch.cuda.device(self.device):
                 spec = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
-                rc = L.sushi_hip_prepare_spectra(self.xc.data_ptr(), self.n, spec.data_ptr(), nbytes,
+                rc = L.sushi_hip_prepare_spectra(self.xc.data_ptr(), self.n, float(os.environ.get('SUSHI_DBG_SPEC_CENTRE', self.centre)), spec.data_ptr(), nbytes,
                                                  _raw_stream(self.device))
                 _native.check(rc, "sushi_hip_prepare_spectra")
             self._spec = spec
         return self._spec
 
     def nbytes(self):
-        return self.xc.numel() * 4 + (self.s1.numel() + self.s2.numel() + self.base.numel()) * 8 + self.rel.numel() * 4 + \
+        return self.xc.numel() * 4 + (self.s1.numel() + self.s2.numel() + self.base.numel()) * 8 + self.urel.numel() * 4 + \
             (0 if self._spec is None else self._spec.numel() * 4)
 
 
@@ -216,7 +217,7 @@ class SearchBatch(object):
         st = _raw_stream(dst.device) if hip_stream is None else hip_stream
         if self.path == "fft":
             rc = L.sushi_hip_match_batch_fft(dst.xc.data_ptr(), dst.s1.data_ptr(), dst.s2.data_ptr(), dst.n,
-                                             dst.rel.data_ptr(), dst.base.data_ptr(), self.spec.data_ptr(),
+                                             dst.urel.data_ptr(), dst.base.data_ptr(), self.spec.data_ptr(),
                                              src.xc.data_ptr(), src.s1.data_ptr(), src.s2.data_ptr(), src.n,
                                              dst.centre, _native.SQDIFF_NORMED,
                                              self.desc.data_ptr(), self.host_desc.ctypes.data, self.n, self.delta,
@@ -236,6 +237,13 @@ class SearchBatch(object):
     def results(self):
         """(idx int32 ndarray, score float32 ndarray) -- synchronises."""
         return self.out_idx.cpu().numpy(), self.out_score.cpu().numpy()
+
+    def ranking_errors(self):
+        """FFT path: |f32 FFT score - exact score| at every search's result position in the last run()
+        (0 for searches the direct kernel finished) -- to be compared with delta / 2."""
+        if self.path != "fft":
+            return np.zeros(self.n, np.float32)
+        return self.keys[self.n:2 * self.n].cpu().numpy().astype(np.uint64).astype(np.uint32).view(np.float32)
 
     def fallback_count(self):
         """FFT path: how many searches of the last run() were finished by the direct kernel."""
