@@ -86,7 +86,7 @@ class DeviceStream(object):
             nbytes = int(L.sushi_hip_spectra_bytes(self.n))
             with torch.cuda.device(self.device):
                 spec = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
-                rc = L.sushi_hip_prepare_spectra(self.xc.data_ptr(), self.n, float(os.environ.get('SUSHI_DBG_SPEC_CENTRE', self.centre)), spec.data_ptr(), nbytes,
+                rc = L.sushi_hip_prepare_spectra(self.xc.data_ptr(), self.n, self.centre, spec.data_ptr(), nbytes,
                                                  _raw_stream(self.device))
                 _native.check(rc, "sushi_hip_prepare_spectra")
             self._spec = spec
