@@ -466,3 +466,17 @@ def test_fft_ranking_error_is_far_below_delta():
         err = b.ranking_errors()
         assert b.fallback_count() == 0
         assert err.max() < b.delta / 8, err.max()
+
+
+@pytest.mark.parametrize("variant", [2, "fft"])
+def test_no_match_anywhere_ties_at_one(oracle, variant):
+    """A destination that is digital silence followed by a nearly silent passage: every window scores >= 1
+    before cv2's clamp, so the result row is all 1.0 and argmin must return index 0 (wav.py:186).  The FFT
+    stage has to clamp too, or it would rank the unclamped values and hand back a later index."""
+    rng = np.random.default_rng(77)
+    dst = np.concatenate((np.zeros(3000, np.float32), (rng.random(30000, dtype=np.float32) * np.float32(1e-3))))
+    src = (np.float32(0.3) + rng.random(4000, dtype=np.float32) * np.float32(0.5)).astype(np.float32)
+    res = oracle.match_template(dst[:28000 + 3999], src)[0]
+    assert res.min() == 1.0 and int(res.argmin()) == 0
+    (idx, score), b = _run_batch(dst, src, [0], [4000], [0], [28000], variant, want_batch=True)
+    assert idx[0] == 0 and score[0] == 1.0
