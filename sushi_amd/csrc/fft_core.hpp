@@ -31,9 +31,17 @@
 namespace sushi_fft {
 
 constexpr int N = 8192;          // transform length (complex points)
-constexpr int NT = 512;          // threads per workgroup
-constexpr int PER = N / NT;      // 16 points per thread
 constexpr int LDS_ELEMS = N + N / 16;   // padded buffer, in complex elements
+
+// Two workgroup shapes share the code below:
+//   Shape<512>: 512 threads x 16 points, radix plan 8 x 8 x 8 x 16  (three LDS exchanges)
+//   Shape<256>: 256 threads x 32 points, radix plan 16 x 16 x 32    (two LDS exchanges, half the waves per barrier)
+template <int NT_> struct Shape {
+    static constexpr int NT = NT_;
+    static constexpr int PER = N / NT_;
+};
+constexpr int NT = 512;          // the default shape's thread count (forward transforms)
+constexpr int PER = N / NT;
 
 struct cpx { float x, y; };
 
@@ -43,20 +51,21 @@ SUSHI_HD cpx cmul(cpx a, cpx b) { return cpx{a.x * b.x - a.y * b.y, a.x * b.y + 
 SUSHI_HD cpx cconj(cpx a) { return cpx{a.x, -a.y}; }
 SUSHI_HD int pad(int e) { return e + (e >> 4); }
 
-// exp(DIR * 2*pi*i * q/16), q = 0..7, as compile-time cases (q is a constant after unrolling)
+// exp(DIR * 2*pi*i * q/32), q = 0..15, as compile-time cases (q is a constant after unrolling)
 template <int DIR>
-SUSHI_HD cpx mul_root16(cpx a, int q) {
-    const float C1 = 0.92387953251128673848f, S1 = 0.38268343236508978178f, H = 0.70710678118654752440f;
+SUSHI_HD cpx mul_root32(cpx a, int q) {
+    const float H = 0.70710678118654752440f;
+    const float C[9] = {1.0f, 0.98078528040323044913f, 0.92387953251128673848f, 0.83146961230254523708f, H,
+                        0.55557023301960222474f, 0.38268343236508978178f, 0.19509032201612826785f, 0.0f};
     const float s = (float)DIR;
     switch (q) {
         case 0: return a;
-        case 1: return cmul(a, cpx{C1, s * S1});
-        case 2: return cpx{H * (a.x - s * a.y), H * (a.y + s * a.x)};
-        case 3: return cmul(a, cpx{S1, s * C1});
-        case 4: return cpx{-s * a.y, s * a.x};
-        case 5: return cmul(a, cpx{-S1, s * C1});
-        case 6: return cpx{-H * (a.x + s * a.y), H * (s * a.x - a.y)};
-        default: return cmul(a, cpx{-C1, s * S1});
+        case 4: return cpx{H * (a.x - s * a.y), H * (a.y + s * a.x)};
+        case 8: return cpx{-s * a.y, s * a.x};
+        case 12: return cpx{-H * (a.x + s * a.y), H * (s * a.x - a.y)};
+        default:
+            // cos(2 pi q / 32) = C[q] (q <= 8), -C[16 - q] (q > 8); sin = C[8 - q] (q <= 8), C[q - 8] (q > 8)
+            return cmul(a, cpx{q <= 8 ? C[q] : -C[16 - q], s * (q <= 8 ? C[8 - q] : C[q - 8])});
     }
 }
 
@@ -71,7 +80,7 @@ struct Dft {
         Dft<R / 2, DIR>::run(o);
 #pragma unroll
         for (int t = 0; t < R / 2; ++t) {
-            const cpx ow = mul_root16<DIR>(o[t], t * (16 / R));
+            const cpx ow = mul_root32<DIR>(o[t], t * (32 / R));
             v[t] = cadd(e[t], ow);
             v[t + R / 2] = csub(e[t], ow);
         }
@@ -82,46 +91,51 @@ struct Dft<1, DIR> {
     static SUSHI_HD void run(cpx*) {}
 };
 
-// Base twiddles of the three twiddled passes for this thread, w^1 = exp(DIR*2*pi*i*k/(NS*R)) with
-// k = j mod NS: the two butterflies of a thread (j = tid, tid + 512) share k in passes 2 and 3, and
-// pass 4 (radix 16) has one butterfly per thread.
-// tw[n] = exp(-2*pi*i*n/N), n = 0..N-1 (the forward table; the inverse conjugates it).
+// Base twiddles of the twiddled passes for this thread, w^1 = exp(DIR*2*pi*i*k/(NS*R)) with k = j mod NS:
+// the butterflies of a thread (j = tid + b*NT) share k in the middle passes, and the last pass has one
+// butterfly per thread.  tw[n] = exp(-2*pi*i*n/N), n = 0..N-1 (the forward table; the inverse conjugates it).
 // Loaded once, before the first barrier, so that no table load sits between two passes.
 struct Twiddles { cpx p2, p3, p4; };
 
-template <int DIR>
+template <int NT_, int DIR>
 SUSHI_HD Twiddles load_twiddles(int tid, const cpx* __restrict__ tw) {
     Twiddles t;
-    t.p2 = tw[(tid & 7) * (N / 64)];
-    t.p3 = tw[(tid & 63) * (N / 512)];
-    t.p4 = tw[tid];
+    if (NT_ == 512) {
+        t.p2 = tw[(tid & 7) * (N / 64)];       // pass 2: R = 8,  NS = 8
+        t.p3 = tw[(tid & 63) * (N / 512)];     // pass 3: R = 8,  NS = 64
+        t.p4 = tw[tid];                        // pass 4: R = 16, NS = 512
+    } else {
+        t.p2 = tw[(tid & 15) * (N / 256)];     // pass 2: R = 16, NS = 16
+        t.p3 = tw[tid];                        // pass 3: R = 32, NS = 256
+        t.p4 = cpx{1.f, 0.f};
+    }
     if (DIR > 0) { t.p2 = cconj(t.p2); t.p3 = cconj(t.p3); t.p4 = cconj(t.p4); }
     return t;
 }
 
 // which butterfly: pass 1 pairs adjacent ones in a thread, the others stride by the workgroup size
-template <bool FIRST>
-SUSHI_HD int butterfly(int tid, int b) { return FIRST ? 2 * tid + b : tid + b * NT; }
+template <int NT_, bool FIRST>
+SUSHI_HD int butterfly(int tid, int b) { return FIRST ? 2 * tid + b : tid + b * NT_; }
 
 // One pass, register side: twiddle (unless NS == 1) and butterfly the PER points of this thread.
-// v[b*R + t] holds input t of the thread's butterfly b; w1 is the base twiddle (shared by both).
-// The powers w^t are built from the squarings w, w^2, w^4, w^8 only (each w^t = product of the squarings
-// its binary digits select, at most three multiplications deep): four live twiddle registers instead of
-// R, which is what lets the radix-16 pass coexist with prefetched loads in a 128-register budget.
-template <int R, int NS, int DIR>
+// v[b*R + t] holds input t of the thread's butterfly b; w1 is the base twiddle (shared by all of them).
+// The powers w^t are built from the squarings w, w^2, w^4, w^8, w^16 only (each w^t = product of the
+// squarings its binary digits select, at most four multiplications deep): five live twiddle registers
+// instead of R, which is what lets the wide last pass coexist with everything else in its register budget.
+template <int PER_, int R, int NS, int DIR>
 SUSHI_HD void pass_compute(cpx* v, const cpx w1) {
-    constexpr int NB = PER / R;
+    constexpr int NB = PER_ / R;
     if (NS > 1) {
-        cpx sq[4];
+        cpx sq[5];
         sq[0] = w1;
 #pragma unroll
-        for (int q = 1; q < 4; ++q) sq[q] = cmul(sq[q - 1], sq[q - 1]);
+        for (int q = 1; q < 5; ++q) sq[q] = cmul(sq[q - 1], sq[q - 1]);
 #pragma unroll
         for (int t = 1; t < R; ++t) {
             cpx wt = cpx{1.f, 0.f};
             bool first = true;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 5; ++q) {
                 if (t & (1 << q)) {
                     wt = first ? sq[q] : cmul(wt, sq[q]);
                     first = false;
@@ -136,73 +150,104 @@ SUSHI_HD void pass_compute(cpx* v, const cpx w1) {
 }
 
 // store the outputs of a pass into the (padded) LDS buffer: element base + t*NS with base = (j-k)*R + k.
-//   NS = 1 : base = 8 j, and a thread's two butterflies (j = 2 tid, 2 tid + 1) fill elements 16 tid .. 16 tid + 15:
-//            pad(16 tid + u) = 17 tid + u
-//   NS = 8 : base = 64 (j >> 3) + k, pad(base + 8 t) = 68 (j >> 3) + k + 8 t + (t >> 1)
-//   NS = 64: base + 64 t, a multiple-of-16 step: pad(base + 64 t) = pad(base) + 68 t
-template <int R, int NS, bool FIRST>
+//   first pass (NS = 1): a thread's butterflies j = 2 tid, 2 tid + 1 fill the PER contiguous elements from
+//            PER*tid on: pad(PER tid + u) = PER tid + (PER/16) tid + u + (u >> 4)
+//   NS = 8 (R = 8)  : base = 64 (j >> 3) + k, pad(base + 8 t)  = 68 (j >> 3) + k + 8 t + (t >> 1)
+//   NS % 16 == 0    : a multiple-of-16 step: pad(base + NS t) = pad(base) + (NS + NS/16) t
+template <int NT_, int R, int NS, bool FIRST>
 SUSHI_HD void pass_store(const cpx* v, int tid, cpx* lds) {
-    constexpr int NB = PER / R;
+    constexpr int PER_ = N / NT_;
+    constexpr int NB = PER_ / R;
     static_assert(NS == 1 || NS == 8 || NS % 16 == 0, "padding arithmetic");
+    static_assert(!FIRST || (NS == 1 && NB == 2), "the first pass pairs two adjacent butterflies per thread");
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const int j = butterfly<FIRST>(tid, b);
+        const int j = butterfly<NT_, FIRST>(tid, b);
         const int k = j & (NS - 1);
         const int base = (j - k) * R + k;
-        cpx* out = lds + (NS == 1 ? base + (base >> 4) : (NS == 8 ? 68 * (j >> 3) + k : pad(base)));
+        if (NS == 1) {
+            cpx* out = lds + PER_ * tid + (PER_ / 16) * tid;
 #pragma unroll
-        for (int t = 0; t < R; ++t)
-            out[NS == 1 ? t : (NS == 8 ? 8 * t + (t >> 1) : t * (NS + NS / 16))] = v[b * R + t];
+            for (int t = 0; t < R; ++t) out[(b * R + t) + ((b * R + t) >> 4)] = v[b * R + t];
+        } else {
+            cpx* out = lds + (NS == 8 ? 68 * (j >> 3) + k : pad(base));
+#pragma unroll
+            for (int t = 0; t < R; ++t) out[NS == 8 ? 8 * t + (t >> 1) : t * (NS + NS / 16)] = v[b * R + t];
+        }
     }
 }
 
 // load the inputs of a radix-R pass from the LDS buffer: pad(j + t*N/R) = pad(j) + t*(N/R + N/R/16)
-template <int R>
+template <int NT_, int R>
 SUSHI_HD void pass_load(cpx* v, int tid, const cpx* lds) {
-    constexpr int NB = PER / R;
+    constexpr int NB = (N / NT_) / R;
     constexpr int STRIDE = N / R;
     static_assert(STRIDE % 16 == 0, "padding arithmetic assumes N/R is a multiple of 16");
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const int j = butterfly<false>(tid, b);
+        const int j = butterfly<NT_, false>(tid, b);
         const cpx* in = lds + pad(j);
 #pragma unroll
         for (int t = 0; t < R; ++t) v[b * R + t] = in[t * (STRIDE + STRIDE / 16)];
     }
 }
 
-// Index maps of the whole transform (what the caller needs to load / interpret registers):
-//   input : v[b*8 + t] = x[2*tid + b + 1024*t]     b = 0..1, t = 0..7   (adjacent pairs: 16-byte loads)
-//   output: v[r]       = X[tid + 512*r]            r = 0..15
-SUSHI_HD int in_index(int tid, int r) { return 2 * tid + (r >> 3) + (N / 8) * (r & 7); }
-SUSHI_HD int out_index(int tid, int r) { return tid + NT * r; }
+// Index maps of the whole transform (what the caller needs to load / interpret registers), R1 = the
+// first radix (8 for Shape<512>, 16 for Shape<256>):
+//   input : v[b*R1 + t] = x[2*tid + b + (N/R1)*t]     b = 0..1, t = 0..R1-1   (adjacent pairs: 16-byte loads)
+//   output: v[r]        = X[tid + NT*r]               r = 0..PER-1
+template <int NT_>
+SUSHI_HD int in_index_t(int tid, int r) {
+    constexpr int R1 = (N / NT_) / 2;
+    return 2 * tid + (r / R1) + (N / R1) * (r % R1);
+}
+template <int NT_>
+SUSHI_HD int out_index_t(int tid, int r) { return tid + NT_ * r; }
+SUSHI_HD int in_index(int tid, int r) { return in_index_t<NT>(tid, r); }
+SUSHI_HD int out_index(int tid, int r) { return out_index_t<NT>(tid, r); }
 
 #ifdef __HIPCC__
 #define SUSHI_FFT_BARRIER() __syncthreads()
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
-// Full transform of the 16 points in v (in_index layout) -> v (out_index layout).
+// Full transform of the PER points in v (in_index layout) -> v (out_index layout).
 // `lds` must hold LDS_ELEMS elements; its contents are dead once the call returns and it may be
-// reused after one further __syncthreads().  `before_last_pass` runs after the third pass's stores and
+// reused after one further __syncthreads().  `before_last_pass` runs after the last exchange's stores and
 // before the last pass: a place to issue independent global loads whose latency the last pass covers.
 template <int DIR, class Hook = NoHook>
 __device__ __forceinline__ void fft8192(cpx* v, int tid, cpx* lds, const Twiddles tw, Hook before_last_pass = Hook()) {
-    pass_compute<8, 1, DIR>(v, cpx{1.f, 0.f});
-    pass_store<8, 1, true>(v, tid, lds);
+    pass_compute<16, 8, 1, DIR>(v, cpx{1.f, 0.f});
+    pass_store<512, 8, 1, true>(v, tid, lds);
     SUSHI_FFT_BARRIER();
-    pass_load<8>(v, tid, lds);
-    pass_compute<8, 8, DIR>(v, tw.p2);
+    pass_load<512, 8>(v, tid, lds);
+    pass_compute<16, 8, 8, DIR>(v, tw.p2);
     SUSHI_FFT_BARRIER();
-    pass_store<8, 8, false>(v, tid, lds);
+    pass_store<512, 8, 8, false>(v, tid, lds);
     SUSHI_FFT_BARRIER();
-    pass_load<8>(v, tid, lds);
-    pass_compute<8, 64, DIR>(v, tw.p3);
+    pass_load<512, 8>(v, tid, lds);
+    pass_compute<16, 8, 64, DIR>(v, tw.p3);
     SUSHI_FFT_BARRIER();
-    pass_store<8, 64, false>(v, tid, lds);
+    pass_store<512, 8, 64, false>(v, tid, lds);
     before_last_pass();
     SUSHI_FFT_BARRIER();
-    pass_load<16>(v, tid, lds);
-    pass_compute<16, 512, DIR>(v, tw.p4);
+    pass_load<512, 16>(v, tid, lds);
+    pass_compute<16, 16, 512, DIR>(v, tw.p4);
+}
+
+// The same transform by 256 threads x 32 points (Shape<256>).
+template <int DIR, class Hook = NoHook>
+__device__ __forceinline__ void fft8192_w256(cpx* v, int tid, cpx* lds, const Twiddles tw, Hook before_last_pass = Hook()) {
+    pass_compute<32, 16, 1, DIR>(v, cpx{1.f, 0.f});
+    pass_store<256, 16, 1, true>(v, tid, lds);
+    SUSHI_FFT_BARRIER();
+    pass_load<256, 16>(v, tid, lds);
+    pass_compute<32, 16, 16, DIR>(v, tw.p2);
+    SUSHI_FFT_BARRIER();
+    pass_store<256, 16, 16, false>(v, tid, lds);
+    before_last_pass();
+    SUSHI_FFT_BARRIER();
+    pass_load<256, 32>(v, tid, lds);
+    pass_compute<32, 32, 256, DIR>(v, tw.p3);
 }
 #endif
 

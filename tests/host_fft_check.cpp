@@ -32,8 +32,9 @@ static void ref_fft(std::vector<cd>& a, int dir) {   // iterative radix-2, float
     }
 }
 
-template <int DIR>
+template <int NTS, int DIR>
 static double run(const std::vector<cpx>& tw, unsigned seed) {
+    constexpr int P = N / NTS;
     std::vector<cpx> x(N);
     srand(seed);
     for (int n = 0; n < N; ++n) {
@@ -43,22 +44,29 @@ static double run(const std::vector<cpx>& tw, unsigned seed) {
     std::vector<cd> r(N);
     for (int n = 0; n < N; ++n) r[n] = cd(x[n].x, x[n].y);
     ref_fft(r, DIR);
-    std::vector<cpx> regs((size_t)NT * PER), lds(LDS_ELEMS);
-    for (int tid = 0; tid < NT; ++tid)
-        for (int q = 0; q < PER; ++q) regs[(size_t)tid * PER + q] = x[in_index(tid, q)];
-#define ALL(stmt) for (int tid = 0; tid < NT; ++tid) { cpx* v = &regs[(size_t)tid * PER]; \
-        const Twiddles t = load_twiddles<DIR>(tid, tw.data()); (void)t; stmt; }
-    ALL((pass_compute<8, 1, DIR>(v, cpx{1.f, 0.f}), pass_store<8, 1, true>(v, tid, lds.data())))
-    ALL((pass_load<8>(v, tid, lds.data()), pass_compute<8, 8, DIR>(v, t.p2)))
-    ALL((pass_store<8, 8, false>(v, tid, lds.data())))
-    ALL((pass_load<8>(v, tid, lds.data()), pass_compute<8, 64, DIR>(v, t.p3)))
-    ALL((pass_store<8, 64, false>(v, tid, lds.data())))
-    ALL((pass_load<16>(v, tid, lds.data()), pass_compute<16, 512, DIR>(v, t.p4)))
+    std::vector<cpx> regs((size_t)NTS * P), lds(LDS_ELEMS);
+    for (int tid = 0; tid < NTS; ++tid)
+        for (int q = 0; q < P; ++q) regs[(size_t)tid * P + q] = x[in_index_t<NTS>(tid, q)];
+#define ALL(stmt) for (int tid = 0; tid < NTS; ++tid) { cpx* v = &regs[(size_t)tid * P]; \
+        const Twiddles t = load_twiddles<NTS, DIR>(tid, tw.data()); (void)t; stmt; }
+    if (NTS == 512) {
+        ALL((pass_compute<16, 8, 1, DIR>(v, cpx{1.f, 0.f}), pass_store<512, 8, 1, true>(v, tid, lds.data())))
+        ALL((pass_load<512, 8>(v, tid, lds.data()), pass_compute<16, 8, 8, DIR>(v, t.p2)))
+        ALL((pass_store<512, 8, 8, false>(v, tid, lds.data())))
+        ALL((pass_load<512, 8>(v, tid, lds.data()), pass_compute<16, 8, 64, DIR>(v, t.p3)))
+        ALL((pass_store<512, 8, 64, false>(v, tid, lds.data())))
+        ALL((pass_load<512, 16>(v, tid, lds.data()), pass_compute<16, 16, 512, DIR>(v, t.p4)))
+    } else {
+        ALL((pass_compute<32, 16, 1, DIR>(v, cpx{1.f, 0.f}), pass_store<256, 16, 1, true>(v, tid, lds.data())))
+        ALL((pass_load<256, 16>(v, tid, lds.data()), pass_compute<32, 16, 16, DIR>(v, t.p2)))
+        ALL((pass_store<256, 16, 16, false>(v, tid, lds.data())))
+        ALL((pass_load<256, 32>(v, tid, lds.data()), pass_compute<32, 32, 256, DIR>(v, t.p3)))
+    }
     double err2 = 0, ref2 = 0;
-    for (int tid = 0; tid < NT; ++tid)
-        for (int q = 0; q < PER; ++q) {
-            const cpx g = regs[(size_t)tid * PER + q];
-            const cd e = r[out_index(tid, q)];
+    for (int tid = 0; tid < NTS; ++tid)
+        for (int q = 0; q < P; ++q) {
+            const cpx g = regs[(size_t)tid * P + q];
+            const cd e = r[out_index_t<NTS>(tid, q)];
             err2 += std::norm(cd(g.x, g.y) - e);
             ref2 += std::norm(e);
         }
@@ -71,7 +79,8 @@ int main() {
         tw[n].x = (float)std::cos(2.0 * M_PI * n / N);
         tw[n].y = (float)-std::sin(2.0 * M_PI * n / N);
     }
-    const double f = run<-1>(tw, 1), b = run<1>(tw, 2);
-    printf("%.3e %.3e\n", f, b);
-    return (f < 1e-6 && b < 1e-6) ? 0 : 1;
+    const double f = run<512, -1>(tw, 1), b = run<512, 1>(tw, 2);
+    const double f2 = run<256, -1>(tw, 3), b2 = run<256, 1>(tw, 4);
+    printf("%.3e %.3e %.3e %.3e\n", f, b, f2, b2);
+    return (f < 1e-6 && b < 1e-6 && f2 < 1e-6 && b2 < 1e-6) ? 0 : 1;
 }
