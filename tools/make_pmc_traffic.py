@@ -10,7 +10,7 @@ import json
 import sys
 
 summary, out, workload = sys.argv[1], sys.argv[2], sys.argv[3]
-rows = {r['kernel']: r for r in csv.DictReader(open(summary))}
+rows = {r['kernel'].split('<')[0]: r for r in csv.DictReader(open(summary))}       # template arguments dropped
 res = {}
 for k, fetch_scale in (('ifft_kernel', 2.0), ('mac_kernel', 2.0), ('tspec_kernel', 1.0), ('refine_kernel', 1.0)):
     if k in rows and rows[k].get('FETCH_SIZE') and rows[k].get('WRITE_SIZE'):
