@@ -480,3 +480,30 @@ def test_no_match_anywhere_ties_at_one(oracle, variant):
     assert res.min() == 1.0 and int(res.argmin()) == 0
     (idx, score), b = _run_batch(dst, src, [0], [4000], [0], [28000], variant, want_batch=True)
     assert idx[0] == 0 and score[0] == 1.0
+
+
+from hypothesis import given, settings, strategies as st
+
+
+@settings(max_examples=40, deadline=None)
+@given(seed=st.integers(0, 2 ** 31 - 1), L=st.integers(1, 30000), frac=st.floats(0.0, 1.0), u8=st.booleans(),
+       path=st.sampled_from([0, 2, "fft"]))
+def test_random_shapes_property(seed, L, frac, u8, path):
+    """Any (search length, pattern length, dtype, path): same arg-min and score as the oracle."""
+    from oracle import oracle as O
+    O.build()
+    M = max(1, min(L, int(round(frac * L))))
+    rng = np.random.default_rng(seed)
+    if u8:
+        dst = rng.integers(0, 256, L + 5, dtype=np.uint8)
+        src = rng.integers(0, 256, M + 3, dtype=np.uint8)
+    else:
+        dst = rng.random(L + 5, dtype=np.float32)
+        src = rng.random(M + 3, dtype=np.float32)
+    if M >= 8 and L - M >= 1:
+        p = int(rng.integers(0, L - M + 1))                  # plant a noisy copy somewhere
+        src[1:1 + M] = dst[2 + p:2 + p + M]
+        src[1 + M // 2] = dst[0]
+    idx, score = _run_batch(dst, src, [1], [M], [2], [L - M + 1], path)
+    res = O.match_template_direct(dst[2:2 + L], src[1:1 + M])[0]
+    (_check_u8 if u8 else _check_f32)(res, idx[0], score[0])

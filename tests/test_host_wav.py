@@ -131,3 +131,27 @@ def test_find_substream_without_gpu_fails_loudly():
     a = WavStream.from_samples((rng.standard_normal(40000) * 1000).astype(np.int16), 12000, sample_type="float32")
     with pytest.raises(SushiError):
         a.find_substream(a.get_substream(0.5, 1.0), 0.5, 1.5)
+
+
+# ---- property tests (hypothesis) of the host window arithmetic against the oracle's wav.py:177-188 restatement ----
+from hypothesis import given, settings, strategies as st
+
+
+@settings(max_examples=300, deadline=None)
+@given(centre=st.floats(min_value=-40.0, max_value=140.0, allow_nan=False),
+       window=st.one_of(st.floats(min_value=0.0, max_value=130.0, allow_nan=False), st.integers(0, 130)),
+       m=st.integers(1, 70000), rate=st.sampled_from([8000, 12000, 24000]))
+def test_window_arithmetic_matches_oracle_for_any_request(centre, window, m, rate):
+    """WavStream._window (start time, first sample, result length) == the oracle's search_bounds for any
+    centre / window / pattern length, including windows clipped at either end and NumPy slice truncation."""
+    from oracle import oracle as O
+    from sushi_amd.wav import WavStream
+    n = 100 * rate
+    w = WavStream.__new__(WavStream)
+    w.data = np.zeros((1, n + 20 * rate), np.uint8)
+    w.sample_rate, w.sample_count, w.padding_size = rate, n, 10 * rate
+    o = O.OracleWavStream(w.data, rate, n, 10 * rate)
+    start_time, lo, n_pos = w._window(m, centre, window)
+    o_start, o_lo, o_hi = o.search_bounds(m, centre, window)
+    assert start_time == o_start and lo == o_lo
+    assert n_pos == max(o_hi - o_lo, 0) - m + 1
