@@ -193,10 +193,13 @@ class SpeculativeStream(object):
     ``_window(pattern_len, centre, window)`` -> (start_time, first sample, P) and ``sample_rate`` /
     ``duration_seconds`` (``sushi_amd.wav.WavStream`` does)."""
 
-    def __init__(self, dst, src, groups_list, lookahead=64):
+    def __init__(self, dst, src, groups_list, lookahead=64, max_lookahead=4096):
         self.dst = dst
         self.src = src
-        self.lookahead = int(lookahead)
+        self.lookahead = int(lookahead)            # groups speculated per launch; doubles while guesses hold
+        self.base_lookahead = int(lookahead)
+        self.max_lookahead = max(int(max_lookahead), int(lookahead))
+        self._last_launch = None                   # (first group, groups speculated) of the previous launch
         self.launches = 0          # batched launches issued
         self.searches = 0          # searches computed (useful + speculative)
         self.requests = 0          # find_substream calls answered
@@ -265,6 +268,13 @@ class SpeculativeStream(object):
         role = self._role.get(key)
         if role is not None and self.lookahead > 0:
             gi, which = role
+            # the previous guess held for every group it covered -> speculate twice as far this time;
+            # it broke early (a chapter boundary, a noisy group) -> back to the base depth
+            if self._last_launch is not None:
+                first, count = self._last_launch
+                self.lookahead = min(2 * self.lookahead, self.max_lookahead) if gi >= first + count \
+                    else self.base_lookahead
+            self._last_launch = (gi, min(self.lookahead, len(self._groups) - gi))
             start_g, _, _, _, roff_g = self._groups[gi]
             offset = centre - start_g - (roff_g if which == 2 else 0.0)     # the shift being probed
             probe_only = (which == 0 and window == SMALL_WINDOW)            # sushi.py:431-432 asks for nothing else
@@ -295,10 +305,10 @@ class SpeculativeStream(object):
 
 
 def calculate_shifts_batched(src_stream, dst_stream, groups_list, normal_window, max_window, rewind_thresh,
-                             lookahead=64):
+                             lookahead=64, max_lookahead=4096):
     """calculate_shifts with the destination stream behind a SpeculativeStream: identical results,
     a handful of batched GPU launches instead of thousands of dependent ones.  Returns the proxy
     (its counters tell how the speculation went)."""
-    proxy = SpeculativeStream(dst_stream, src_stream, groups_list, lookahead=lookahead)
+    proxy = SpeculativeStream(dst_stream, src_stream, groups_list, lookahead=lookahead, max_lookahead=max_lookahead)
     calculate_shifts(src_stream, proxy, groups_list, normal_window, max_window, rewind_thresh)
     return proxy

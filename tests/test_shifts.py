@@ -159,3 +159,16 @@ def test_config4_chapters_on_gpu_matches_oracle_run(oracle, sample_type):
     ev_seq = _fresh(events[:12])
     r_seq, _ = _run(calculate_shifts, src, dst, ev_seq, 10, 30, 5)
     assert r_seq == r_gpu[:12]
+
+
+def test_lookahead_grows_while_the_shift_holds(oracle):
+    """A constant offset: the speculation depth doubles after every fully used batch, so 80 groups need
+    a handful of launches; results equal the sequential run."""
+    OracleBackedStream.oracle = oracle
+    src, dst, events, _ = _scenario(2000, 200, [(0.0, 2.5)], 90, "uint8", OracleBackedStream, seed=11, max_len=2.0)
+    ev_a, ev_b = _fresh(events), _fresh(events)
+    ra, _ = _run(calculate_shifts, src, dst, ev_a, 10, 30, 5)
+    rb, proxy = _run(calculate_shifts_batched, src, dst, ev_b, 10, 30, 5, lookahead=4)
+    assert ra == rb
+    assert len(events) >= 40 and proxy.launches <= 6           # 4 + 8 + 16 + 32 instead of n / 4
+    assert proxy.lookahead > 4
