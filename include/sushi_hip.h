@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SUSHI_HIP_ABI_VERSION 3
+#define SUSHI_HIP_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define SUSHI_HIP_API __attribute__((visibility("default")))
@@ -86,11 +86,13 @@ SUSHI_HIP_API int sushi_hip_variant_tile_positions(int variant);
 
 /* Stream preparation.  raw_dev: n samples of `dtype` (the row WavStream.data[0]).
  * Outputs: xc_dev[n] float32 = sample - centre (centre = 0.5 for float32 data in [0,1],
- * 128 for uint8); s1_dev[n+1] / s2_dev[n+1] float64 exclusive prefix sums of xc and xc^2 (the CV_64F
- * integral cv2 builds per call); and the window energies in the cheap form the FFT path's scoring
- * reads: urel_dev[n+1] float32 and base_dev[0 .. nb] float64, nb = ceil(n / B), B = sushi_hip_fft_hop():
- *     sum_{e' < e} sample[e']^2 = base[e / B] + urel[e]          (e = 0 .. n; UNCENTRED samples)
- * (base_dev holds 3 * (nb + 1) doubles; the other two thirds are scratch of this call.)
+ * 128 for uint8: what the direct MFMA kernel multiplies); s1_dev[n+1] / s2_dev[n+1] float64 exclusive
+ * prefix sums of the samples and their squares AS THEY ARE (the CV_64F integral cv2 builds per call; exact
+ * for uint8); and the window energies in the cheap form the FFT path's scoring reads: urel_dev[n+1]
+ * float32 and base_dev[0 .. nb] float64, nb = ceil(n / B), B = sushi_hip_fft_hop():
+ *     s2[e] = sum_{e' < e} sample[e']^2 = base[e / B] + urel[e]          (e = 0 .. n)
+ * (base_dev holds 2 * (nb + 1) doubles; the second half is scratch of this call.)
+ * raw_dev stays the caller's: the FFT path reads it again (spectra, template spectra, exact refinement).
  * xc_dev must be 16-byte aligned; base_bytes >= sushi_hip_prepare_base_bytes(n). */
 SUSHI_HIP_API size_t sushi_hip_prepare_base_bytes(int64_t n);
 SUSHI_HIP_API double sushi_hip_centre(int dtype);
@@ -102,6 +104,11 @@ SUSHI_HIP_API int sushi_hip_prepare_stream(const void* raw_dev, int dtype, int64
  *   dst_* : prepared search stream (the WavStream find_substream is called on), dst_len samples
  *   src_* : prepared stream the patterns are slices of, src_len samples
  *   centre: the value subtracted by sushi_hip_prepare_stream for these streams' dtype
+ *           (the cross terms are accumulated in float32 over xc = sample - centre: exact for uint8; for
+ *           float32 the rounding is relative to sum |T - 0.5| |I - 0.5|, which is what makes the kernel at
+ *           least as accurate as cv2 on WavStream data -- silence sits at the mid level -- but not on
+ *           windows of samples near 0, where sum T I is small itself and float32(sample - 0.5) drops low
+ *           bits; sushi_hip_match_batch_fft reads the samples themselves and has no such limit)
  *   searches_dev[n_search], ordered by first_tile; n_tiles = total tile count
  *   keys_ws_dev[n_search] : uint64 scratch
  *   out_idx_dev[n_search]   = result.argmin(axis=1)[0]        (wav.py:186)
@@ -117,7 +124,7 @@ SUSHI_HIP_API int sushi_hip_match_batch(const float* dst_xc_dev, const double* d
 
 /* ---- overlap-save FFT path ------------------------------------------------------------------
  * The destination stream is cut into blocks of sushi_hip_fft_hop() = B samples; block j is
- * stored as the 2B-point complex DFT of x[jB .. jB+2B) + i * x[(j+1)B .. (j+3)B) (x = xc + centre; zeros past
+ * stored as the 2B-point complex DFT of x[jB .. jB+2B) + i * x[(j+1)B .. (j+3)B) (x = the samples as they are; zeros past
  * the end), 2B complex float32 each, followed by one all-zero block:
  * sushi_hip_spectra_bytes(n) = (ceil(n/B) + 1) * 2B * 8 bytes.
  * A search covers the blocks floor(win_start/B) .. floor((win_start+n_pos-1)/B), two per
@@ -139,12 +146,14 @@ SUSHI_HIP_API size_t sushi_hip_fft_workspace_bytes(int64_t n_pairs, int64_t n_se
 SUSHI_HIP_API int sushi_hip_fft_pair_order(const SushiHipSearch* searches_host, int n_search, size_t ws_bytes,
                              int32_t* order_host, int64_t order_len);
 
-/* xc_dev: centred stream from sushi_hip_prepare_stream (16-byte aligned); the spectra are those of the
- * uncentred samples xc + centre; spec_dev: output. */
-SUSHI_HIP_API int sushi_hip_prepare_spectra(const float* xc_dev, int64_t n, double centre, void* spec_dev, size_t spec_bytes,
+/* raw_dev: the stream's samples as they are (uint8 or float32, as given to sushi_hip_prepare_stream);
+ * spec_dev: output (16-byte aligned). */
+SUSHI_HIP_API int sushi_hip_prepare_spectra(const void* raw_dev, int dtype, int64_t n, void* spec_dev, size_t spec_bytes,
                                             void* hip_stream);
 
 /* Same results as sushi_hip_match_batch.  Additional arguments:
+ *   dst_raw_dev / src_raw_dev / dtype : the two streams' samples as they were given to
+ *                       sushi_hip_prepare_stream (template spectra and the exact refinement read them)
  *   dst_urel_dev / dst_base_dev : the relative window-energy prefix and its block bases of the dst stream
  *   dst_spec_dev      : sushi_hip_prepare_spectra output for the dst stream
  *   searches_host     : the same n_search descriptors in host memory (read during the call only);
@@ -165,7 +174,7 @@ SUSHI_HIP_API int sushi_hip_prepare_spectra(const float* xc_dev, int64_t n, doub
 SUSHI_HIP_API int sushi_hip_match_batch_fft(const float* dst_xc_dev, const double* dst_s1_dev, const double* dst_s2_dev, int64_t dst_len,
                               const float* dst_urel_dev, const double* dst_base_dev, const void* dst_spec_dev,
                               const float* src_xc_dev, const double* src_s1_dev, const double* src_s2_dev, int64_t src_len,
-                              double centre, int method,
+                              const void* dst_raw_dev, const void* src_raw_dev, int dtype, int method,
                               const SushiHipSearch* searches_dev, const SushiHipSearch* searches_host,
                               int n_search, double delta,
                               void* ws_dev, size_t ws_bytes,

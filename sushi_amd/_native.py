@@ -18,7 +18,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sushi_hip.h")
 U8, F32 = 0, 1
 SQDIFF_NORMED = 0
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NSTAGES = 5
 STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish")
 
@@ -78,9 +78,9 @@ def lib():
     L.sushi_hip_fft_workspace_bytes.restype = sz
     L.sushi_hip_fft_workspace_bytes.argtypes = [i64, i64, i64]
     L.sushi_hip_prepare_spectra.restype = ci
-    L.sushi_hip_prepare_spectra.argtypes = [vp, i64, dbl, vp, sz, vp]
+    L.sushi_hip_prepare_spectra.argtypes = [vp, ci, i64, vp, sz, vp]
     L.sushi_hip_match_batch_fft.restype = ci
-    L.sushi_hip_match_batch_fft.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, dbl, ci, vp, vp, ci, dbl,
+    L.sushi_hip_match_batch_fft.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, ci, ci, vp, vp, ci, dbl,
                                             vp, sz, vp, vp, vp, vp, vp, vp]
     L.sushi_hip_fft_pair_order.restype = ci
     L.sushi_hip_fft_pair_order.argtypes = [vp, ci, sz, vp, i64]

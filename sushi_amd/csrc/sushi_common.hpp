@@ -65,11 +65,12 @@ __device__ __forceinline__ float key_score(unsigned long long key) { return __ui
 __device__ __forceinline__ unsigned key_pos(unsigned long long key) { return (unsigned)(key & 0xffffffffull); }
 
 // Template statistics in the order cv2 derives them (templmatch.cpp common_matchTemplate:
-// meanStdDev -> templSum2 / templNorm), from the centred float64 prefix sums of the source stream.
+// meanStdDev -> templSum2 / templNorm), from the float64 prefix sums of the source stream's samples
+// (s1 = sum x, s2 = sum x^2 of the samples as they are: exact for uint8, correctly rounded for float32).
 struct TemplStats {
-    double tS1, tS2;      // sum T', sum T'^2 (centred samples)
-    double cM;            // centre^2 * M
-    double tU, tnorm;     // templSum2, templNorm (uncentred, as cv2 has them)
+    double tS1;           // sum T
+    double cM;            // centre^2 * M (what the direct kernel's centred cross term has to be corrected by)
+    double tU, tnorm;     // templSum2, templNorm as cv2 has them
 };
 
 __device__ __forceinline__ TemplStats templ_stats(const double* __restrict__ s1, const double* __restrict__ s2,
@@ -77,11 +78,9 @@ __device__ __forceinline__ TemplStats templ_stats(const double* __restrict__ s1,
     TemplStats t;
     t.cM = centre * centre * (double)M;
     t.tS1 = s1[off + M] - s1[off];
-    t.tS2 = s2[off + M] - s2[off];
-    const double t_sum = t.tS1 + centre * (double)M;                 // sum T   (uncentred)
-    const double t_sq = t.tS2 + 2.0 * centre * t.tS1 + t.cM;         // sum T^2 (uncentred)
+    const double t_sq = s2[off + M] - s2[off];                       // sum T^2
     const double invArea = 1.0 / (double)M;
-    const double t_mean = t_sum * invArea;
+    const double t_mean = t.tS1 * invArea;
     double t_var = t_sq * invArea - t_mean * t_mean;
     t_var = t_var > 0.0 ? t_var : 0.0;
     const double t_sdv = sqrt(t_var);
@@ -92,7 +91,7 @@ __device__ __forceinline__ TemplStats templ_stats(const double* __restrict__ s1,
 }
 
 // OpenCV templmatch.cpp common_matchTemplate(), TM_SQDIFF_NORMED branch, one position.
-// corr_u: sum T*I (uncentred), wU: sum I^2 over the window, tU: sum T^2, tnorm: sqrt(tU).
+// corr_u: sum T*I, wU: sum I^2 over the window, tU: sum T^2, tnorm: sqrt(tU).
 __device__ __forceinline__ float finish_sqdiff_normed(double corr_u, double wU, double tU, double tnorm) {
     double num = (double)(float)corr_u;          // cv2 keeps corr in its float32 result Mat
     num = wU - 2.0 * num + tU;
@@ -107,16 +106,22 @@ __device__ __forceinline__ float finish_sqdiff_normed(double corr_u, double wU, 
     return (float)r;
 }
 
-// Exact score of one position from its centred cross term and the float64 prefix sums
-// (the epilogue of both paths): returns the float32 cv2 would store at result[0][p].
+// Score of one position from the cross term of the CENTRED samples xc = x - centre (what the direct MFMA
+// kernel accumulates) and the float64 prefix sums (w1, w2: the destination stream's, offset to the window):
+// sum T*I = sum T'I' + centre * (sum T + sum I) - centre^2 * M.  Returns the float32 cv2 would store at result[0][p].
 __device__ __forceinline__ float score_at(double corr_c, const TemplStats& t, double centre,
                                           const double* __restrict__ w1, const double* __restrict__ w2,
                                           int64_t p, int M) {
     const double wS1 = w1[p + M] - w1[p];
-    const double wS2 = w2[p + M] - w2[p];
-    const double wU = wS2 + 2.0 * centre * wS1 + t.cM;               // sum I^2 over the window
-    const double corr_u = corr_c + centre * (t.tS1 + wS1) + t.cM;    // sum T*I
+    const double wU = w2[p + M] - w2[p];                             // sum I^2 over the window
+    const double corr_u = corr_c + centre * (t.tS1 + wS1) - t.cM;    // sum T*I
     return finish_sqdiff_normed(corr_u, wU, t.tU, t.tnorm);
+}
+
+// Score of one position from the exact cross term of the samples themselves (refine_kernel).
+__device__ __forceinline__ float score_exact(double corr_u, const TemplStats& t, const double* __restrict__ w2,
+                                             int64_t p, int M) {
+    return finish_sqdiff_normed(corr_u, w2[p + M] - w2[p], t.tU, t.tnorm);
 }
 
 // Overlap-save layout of one search (DESIGN.md "FFT path"); the host twin is sushi_hip_fft_layout().

@@ -324,29 +324,33 @@ void refine_kernel(RefineArgs a) {
     const int n = cnt;
     const int M = sd.tmpl_len;
     const TemplStats ts = templ_stats(a.r.src_s1, a.r.src_s2, sd.tmpl_off, M, a.r.centre);
-    const double* __restrict__ w1 = a.r.dst_s1 + sd.win_start;
     const double* __restrict__ w2 = a.r.dst_s2 + sd.win_start;
-    const float* __restrict__ src = a.r.src_xc + sd.tmpl_off;
     unsigned long long best = NO_KEY;
     float best_approx = 0.f;
     for (int k = 0; k < n; ++k) {
         const unsigned p = key_pos(list[k]);
-        const float* __restrict__ d = a.r.dst_xc + sd.win_start + p;
         double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-        int m = tid;
-        for (; m + 768 < M; m += 1024) {
-            acc0 += (double)src[m] * (double)d[m];
-            acc1 += (double)src[m + 256] * (double)d[m + 256];
-            acc2 += (double)src[m + 512] * (double)d[m + 512];
-            acc3 += (double)src[m + 768] * (double)d[m + 768];
-        }
-        for (; m < M; m += 256) acc0 += (double)src[m] * (double)d[m];
+        // sum T*I over the samples as they are: products of two float32 (or uint8) values are exact in float64
+        auto dot = [&](auto src, auto d) {
+            int m = tid;
+            for (; m + 768 < M; m += 1024) {
+                acc0 += (double)src[m] * (double)d[m];
+                acc1 += (double)src[m + 256] * (double)d[m + 256];
+                acc2 += (double)src[m + 512] * (double)d[m + 512];
+                acc3 += (double)src[m + 768] * (double)d[m + 768];
+            }
+            for (; m < M; m += 256) acc0 += (double)src[m] * (double)d[m];
+        };
+        if (a.r.dtype == SUSHI_HIP_F32)
+            dot((const float*)a.r.src_raw + sd.tmpl_off, (const float*)a.r.dst_raw + sd.win_start + p);
+        else
+            dot((const uint8_t*)a.r.src_raw + sd.tmpl_off, (const uint8_t*)a.r.dst_raw + sd.win_start + p);
         double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
         if ((tid & 63) == 0) part[tid >> 6] = acc;
         __syncthreads();
         if (tid == 0) {
-            const double corr_c = (part[0] + part[1]) + (part[2] + part[3]);
-            const float score = score_at(corr_c, ts, a.r.centre, w1, w2, (int64_t)p, M);
+            const double corr_u = (part[0] + part[1]) + (part[2] + part[3]);
+            const float score = score_exact(corr_u, ts, w2, (int64_t)p, M);
             const unsigned long long key = make_key(score, p);
             if (key < best) { best = key; best_approx = key_score(list[k]); }
         }
@@ -375,33 +379,30 @@ template <> __device__ __forceinline__ float centred<uint8_t>(uint8_t x) { retur
 template <typename T>
 __global__ __launch_bounds__(PB_THREADS)
 void centre_blocksum_kernel(const T* __restrict__ raw, int64_t n, float* __restrict__ xc,
-                            double* __restrict__ bs1, double* __restrict__ bs2, double* __restrict__ bs3) {
-    __shared__ double r1[PB_THREADS / 64], r2[PB_THREADS / 64], r3[PB_THREADS / 64];
+                            double* __restrict__ bs1, double* __restrict__ bs2) {
+    __shared__ double r1[PB_THREADS / 64], r2[PB_THREADS / 64];
     const int64_t base = (int64_t)blockIdx.x * PB;
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    double s1 = 0.0, s2 = 0.0;
 #pragma unroll 4
     for (int k = 0; k < PB_PER_THREAD; ++k) {
         const int64_t e = base + (int64_t)k * PB_THREADS + threadIdx.x;   // coalesced
         if (e < n) {
-            const float v = centred<T>(raw[e]);
-            const double u = (double)(float)raw[e];                       // the uncentred sample
-            xc[e] = v;
-            s1 += (double)v;
-            s2 += (double)v * (double)v;
-            s3 += u * u;
+            const T x = raw[e];
+            const double u = (double)x;                                   // the sample as it is
+            xc[e] = centred<T>(x);                                        // what the direct kernel multiplies
+            s1 += u;
+            s2 += u * u;
         }
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
-    s3 = wave_sum(s3);
-    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; r3[threadIdx.x >> 6] = s3; }
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double t1 = 0.0, t2 = 0.0, t3 = 0.0;
-        for (int w = 0; w < PB_THREADS / 64; ++w) { t1 += r1[w]; t2 += r2[w]; t3 += r3[w]; }
+        double t1 = 0.0, t2 = 0.0;
+        for (int w = 0; w < PB_THREADS / 64; ++w) { t1 += r1[w]; t2 += r2[w]; }
         bs1[blockIdx.x] = t1;
         bs2[blockIdx.x] = t2;
-        bs3[blockIdx.x] = t3;
     }
 }
 
@@ -442,51 +443,47 @@ void scan_blocksums_kernel(double* __restrict__ bs, int stride, int nb) {
     if (tid < NA) bs[tid * stride + nb] = carry[tid];
 }
 
-// prefix sums s1/s2 of the centred samples (float64, absolute) and, for the FFT path's scoring, the
-// prefix sum of the UNCENTRED squares as float32 relative to the base of the sample's PB-block:
-//     sum_{e' < e} x[e']^2 = ubase[e / PB] + urel[e]          (e = 0 .. n)
+// prefix sums s1 = sum x, s2 = sum x^2 of the samples as they are (float64, absolute: exact for uint8) and,
+// for the FFT path's scoring, s2 again as float32 relative to the base of the sample's PB-block:
+//     s2[e] = base2[e / PB] + urel[e]          (e = 0 .. n)
+template <typename T>
 __global__ __launch_bounds__(PB_THREADS)
-void final_scan_kernel(const float* __restrict__ xc, int64_t n, const double* __restrict__ bs1,
+void final_scan_kernel(const T* __restrict__ raw, int64_t n, const double* __restrict__ bs1,
                        const double* __restrict__ bs2, double* __restrict__ s1, double* __restrict__ s2,
-                       float* __restrict__ urel, double centre) {
-    __shared__ double w1[PB_THREADS / 64], w2[PB_THREADS / 64], w3[PB_THREADS / 64];
+                       float* __restrict__ urel) {
+    __shared__ double w1[PB_THREADS / 64], w2[PB_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * PB + (int64_t)tid * PB_PER_THREAD;  // 16 consecutive samples
-    float v[PB_PER_THREAD];
-    double l1 = 0.0, l2 = 0.0, l3 = 0.0;
+    double v[PB_PER_THREAD];
+    double l1 = 0.0, l2 = 0.0;
 #pragma unroll
     for (int k = 0; k < PB_PER_THREAD; ++k) {
         const int64_t e = base + k;
-        v[k] = e < n ? xc[e] : 0.f;
-        const double u = e < n ? (double)(float)(v[k] + (float)centre) : 0.0;
-        l1 += (double)v[k];
-        l2 += (double)v[k] * (double)v[k];
-        l3 += u * u;
+        v[k] = e < n ? (double)raw[e] : 0.0;
+        l1 += v[k];
+        l2 += v[k] * v[k];
     }
-    double t1, t2, t3;
+    double t1, t2;
     double e1 = wave_excl_scan(l1, &t1);
     double e2 = wave_excl_scan(l2, &t2);
-    double e3 = wave_excl_scan(l3, &t3);
-    if (lane == 0) { w1[wv] = t1; w2[wv] = t2; w3[wv] = t3; }
+    if (lane == 0) { w1[wv] = t1; w2[wv] = t2; }
     __syncthreads();
-    for (int w = 0; w < wv; ++w) { e1 += w1[w]; e2 += w2[w]; e3 += w3[w]; }   // prefix inside the block, before sample `base`
-    const double o1 = bs1[blockIdx.x], o2 = bs2[blockIdx.x];                  // block bases
+    for (int w = 0; w < wv; ++w) { e1 += w1[w]; e2 += w2[w]; }        // prefix inside the block, before sample `base`
+    const double o1 = bs1[blockIdx.x], o2 = bs2[blockIdx.x];          // block bases
     if (blockIdx.x == 0 && tid == 0) {
         s1[0] = 0.0; s2[0] = 0.0;
-        if (n % PB == 0) urel[n] = 0.f;                                       // sample n opens a block of its own: ubase[n / PB] = total
+        if (n % PB == 0) urel[n] = 0.f;                               // sample n opens a block of its own: base2[n / PB] = total
     }
 #pragma unroll
     for (int k = 0; k < PB_PER_THREAD; ++k) {
         const int64_t e = base + k;
         if (e < n) {
-            urel[e] = (float)e3;
-            const double u = (double)(float)(v[k] + (float)centre);
-            e1 += (double)v[k];
-            e2 += (double)v[k] * (double)v[k];
-            e3 += u * u;
+            urel[e] = (float)e2;
+            e1 += v[k];
+            e2 += v[k] * v[k];
             s1[e + 1] = o1 + e1;
             s2[e + 1] = o2 + e2;
-            if (e + 1 == n && (n % PB) != 0) urel[n] = (float)e3;
+            if (e + 1 == n && (n % PB) != 0) urel[n] = (float)e2;
         }
     }
 }
@@ -578,7 +575,7 @@ double sushi_hip_centre(int dtype) { return dtype == SUSHI_HIP_U8 ? 128.0 : 0.5;
 size_t sushi_hip_prepare_base_bytes(int64_t n) {
     if (n < 0) return 0;
     const int64_t nb = (n + PB - 1) / PB;
-    return (size_t)(3 * (nb + 1)) * sizeof(double);
+    return (size_t)(2 * (nb + 1)) * sizeof(double);
 }
 
 int sushi_hip_prepare_stream(const void* raw_dev, int dtype, int64_t n, float* xc_dev, double* s1_dev,
@@ -586,27 +583,30 @@ int sushi_hip_prepare_stream(const void* raw_dev, int dtype, int64_t n, float* x
     if (!raw_dev || !xc_dev || !s1_dev || !s2_dev || !urel_dev || !base_dev || n <= 0) return SUSHI_HIP_EINVAL;
     if (dtype != SUSHI_HIP_U8 && dtype != SUSHI_HIP_F32) return SUSHI_HIP_EINVAL;
     if (((uintptr_t)xc_dev & 15) || ((uintptr_t)s1_dev & 7) || ((uintptr_t)s2_dev & 7) || ((uintptr_t)base_dev & 7) ||
-        ((uintptr_t)urel_dev & 3))
+        ((uintptr_t)urel_dev & 3) || (dtype == SUSHI_HIP_F32 && ((uintptr_t)raw_dev & 3)))
         return SUSHI_HIP_EALIGN;
     if (base_bytes < sushi_hip_prepare_base_bytes(n)) return SUSHI_HIP_ENOSPACE;
     const int64_t nb64 = (n + PB - 1) / PB;
     if (nb64 > 0x7ffffffe) return SUSHI_HIP_EINVAL;
     const int nb = (int)nb64;
     hipStream_t st = (hipStream_t)hip_stream;
-    double* ub = base_dev;                       // [0]: block bases of the uncentred squares (what the FFT path reads)
-    double* bs1 = base_dev + (nb + 1);           // [1], [2]: block bases of the centred sums (scratch of this call)
-    double* bs2 = bs1 + (nb + 1);
+    double* bs2 = base_dev;                      // block bases of sum x^2 (what the FFT path's scoring reads)
+    double* bs1 = base_dev + (nb + 1);           // block bases of sum x
     if (dtype == SUSHI_HIP_F32)
         hipLaunchKernelGGL(centre_blocksum_kernel<float>, dim3(nb), dim3(PB_THREADS), 0, st,
-                           (const float*)raw_dev, n, xc_dev, bs1, bs2, ub);
+                           (const float*)raw_dev, n, xc_dev, bs1, bs2);
     else
         hipLaunchKernelGGL(centre_blocksum_kernel<uint8_t>, dim3(nb), dim3(PB_THREADS), 0, st,
-                           (const uint8_t*)raw_dev, n, xc_dev, bs1, bs2, ub);
+                           (const uint8_t*)raw_dev, n, xc_dev, bs1, bs2);
     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-    hipLaunchKernelGGL(scan_blocksums_kernel<3>, dim3(1), dim3(1024), 0, st, base_dev, nb + 1, nb);
+    hipLaunchKernelGGL(scan_blocksums_kernel<2>, dim3(1), dim3(1024), 0, st, base_dev, nb + 1, nb);
     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-    hipLaunchKernelGGL(final_scan_kernel, dim3(nb), dim3(PB_THREADS), 0, st, (const float*)xc_dev, n,
-                       (const double*)bs1, (const double*)bs2, s1_dev, s2_dev, urel_dev, sushi_hip_centre(dtype));
+    if (dtype == SUSHI_HIP_F32)
+        hipLaunchKernelGGL(final_scan_kernel<float>, dim3(nb), dim3(PB_THREADS), 0, st, (const float*)raw_dev, n,
+                           (const double*)bs1, (const double*)bs2, s1_dev, s2_dev, urel_dev);
+    else
+        hipLaunchKernelGGL(final_scan_kernel<uint8_t>, dim3(nb), dim3(PB_THREADS), 0, st, (const uint8_t*)raw_dev, n,
+                           (const double*)bs1, (const double*)bs2, s1_dev, s2_dev, urel_dev);
     return launch_ok();
 }
 
@@ -630,6 +630,7 @@ int sushi_hip_match_batch(const float* dst_xc_dev, const double* dst_s1_dev, con
     r.dst_xc = dst_xc_dev; r.dst_s1 = dst_s1_dev; r.dst_s2 = dst_s2_dev; r.dst_len = dst_len;
     r.src_xc = src_xc_dev; r.src_s1 = src_s1_dev; r.src_s2 = src_s2_dev; r.src_len = src_len;
     r.centre = centre;
+    r.dst_raw = nullptr; r.src_raw = nullptr; r.dtype = SUSHI_HIP_F32;
     const MatchArgs a = match_args(r, searches_dev, n_search, n_tiles, (unsigned long long*)keys_ws_dev);
     switch (variant) {
         case 0: hipLaunchKernelGGL((match_sqdiff_f32_kernel<1, 1>), dim3(n_tiles), dim3(64), 0, st, a); break;

@@ -14,6 +14,7 @@ struct StreamRefs {
     const float* dst_xc; const double* dst_s1; const double* dst_s2; int64_t dst_len;
     const float* src_xc; const double* src_s1; const double* src_s2; int64_t src_len;
     double centre;
+    const void* dst_raw; const void* src_raw; int dtype;     // the samples as they are (refine_kernel); may be null for the direct path
 };
 
 // Exact float64 evaluation of the candidates of searches [first_search, first_search + n_sub).

@@ -31,7 +31,7 @@ def _raw_stream(device):
 class DeviceStream(object):
     """HBM-resident, match-ready form of a 1-D sample row (uint8 or float32)."""
 
-    def __init__(self, samples, device=None, keep_raw=False):
+    def __init__(self, samples, device=None):
         """`samples`: a host array (1-D or (1, N), uint8 / float32) -- uploaded -- or a 1-D torch tensor
         of those dtypes that already lives on the GPU (used as is)."""
         on_device = isinstance(samples, torch.Tensor)
@@ -75,8 +75,7 @@ class DeviceStream(object):
                                             self.urel.data_ptr(), self.base.data_ptr(), base_bytes,
                                             _raw_stream(self.device))
             _native.check(rc, "sushi_hip_prepare_stream")
-            torch.cuda.current_stream(self.device).synchronize()   # raw may be freed now
-        self.raw = raw if keep_raw else None
+        self.raw = raw             # the FFT path reads the samples themselves (spectra, exact refinement)
         self._spec = None
 
     def spectra(self):
@@ -86,14 +85,14 @@ class DeviceStream(object):
             nbytes = int(L.sushi_hip_spectra_bytes(self.n))
             with torch.cuda.device(self.device):
                 spec = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
-                rc = L.sushi_hip_prepare_spectra(self.xc.data_ptr(), self.n, self.centre, spec.data_ptr(), nbytes,
+                rc = L.sushi_hip_prepare_spectra(self.raw.data_ptr(), self.dtype_code, self.n, spec.data_ptr(), nbytes,
                                                  _raw_stream(self.device))
                 _native.check(rc, "sushi_hip_prepare_spectra")
             self._spec = spec
         return self._spec
 
     def nbytes(self):
-        return self.xc.numel() * 4 + (self.s1.numel() + self.s2.numel() + self.base.numel()) * 8 + self.urel.numel() * 4 + \
+        return self.raw.numel() * self.raw.element_size() + self.xc.numel() * 4 + (self.s1.numel() + self.s2.numel() + self.base.numel()) * 8 + self.urel.numel() * 4 + \
             (0 if self._spec is None else self._spec.numel() * 4)
 
 
@@ -219,7 +218,8 @@ class SearchBatch(object):
             rc = L.sushi_hip_match_batch_fft(dst.xc.data_ptr(), dst.s1.data_ptr(), dst.s2.data_ptr(), dst.n,
                                              dst.urel.data_ptr(), dst.base.data_ptr(), self.spec.data_ptr(),
                                              src.xc.data_ptr(), src.s1.data_ptr(), src.s2.data_ptr(), src.n,
-                                             dst.centre, _native.SQDIFF_NORMED,
+                                             dst.raw.data_ptr(), src.raw.data_ptr(), dst.dtype_code,
+                                             _native.SQDIFF_NORMED,
                                              self.desc.data_ptr(), self.host_desc.ctypes.data, self.n, self.delta,
                                              self.ws.data_ptr(), self.ws_bytes,
                                              self.keys.data_ptr(), self.flags.data_ptr(), self.order.data_ptr(),

@@ -80,15 +80,15 @@ def test_prepare_stream(dtype, n):
     c = 128.0 if dtype == np.uint8 else 0.5
     xc = (x.astype(np.float32) - np.float32(c))
     assert (d.xc.cpu().numpy() == xc).all()
-    s1 = np.concatenate(([0.0], np.cumsum(xc.astype(np.float64))))
-    s2 = np.concatenate(([0.0], np.cumsum(xc.astype(np.float64) ** 2)))
+    s1 = np.concatenate(([0.0], np.cumsum(x.astype(np.float64))))        # of the samples as they are
+    s2 = np.concatenate(([0.0], np.cumsum(x.astype(np.float64) ** 2)))
     g1, g2 = d.s1.cpu().numpy(), d.s2.cpu().numpy()
     if dtype == np.uint8:
         assert (g1 == s1).all() and (g2 == s2).all()          # integers: exact in any summation order
     else:
         np.testing.assert_allclose(g1, s1, rtol=0, atol=1e-9 * max(1.0, np.abs(s1).max()))
         np.testing.assert_allclose(g2, s2, rtol=1e-11, atol=1e-9)   # np.cumsum itself rounds sequentially
-    # window energies for the FFT path: prefix of the UNCENTRED squares = ubase[e // 4096] + urel[e]
+    # window energies for the FFT path: s2[e] = ubase[e // 4096] + urel[e]
     nb = (n + 4095) // 4096
     ubase = d.base.cpu().numpy()[:nb + 1]
     urel = d.urel.cpu().numpy()
@@ -485,11 +485,16 @@ def test_no_match_anywhere_ties_at_one(oracle, variant):
 from hypothesis import given, settings, strategies as st
 
 
-@settings(max_examples=40, deadline=None)
+@settings(max_examples=100, deadline=None)
 @given(seed=st.integers(0, 2 ** 31 - 1), L=st.integers(1, 30000), frac=st.floats(0.0, 1.0), u8=st.booleans(),
-       path=st.sampled_from([0, 2, "fft"]))
-def test_random_shapes_property(seed, L, frac, u8, path):
-    """Any (search length, pattern length, dtype, path): same arg-min and score as the oracle."""
+       path=st.sampled_from([0, 2, "fft"]), scale=st.sampled_from([1.0, 1e-3, 1e-6, 40.0]))
+def test_random_shapes_property(seed, L, frac, u8, path, scale):
+    """Any (search length, pattern length, dtype, path): same arg-min and score as the oracle.
+    The FFT path (the default) reads the samples as they are, so it is also held to float32 data of any
+    magnitude; the direct MFMA kernel accumulates float32(sample - 0.5) products, whose rounding is relative
+    to sum |T - 0.5| |I - 0.5| rather than to sum T I, and is held to what WavStream produces: samples around
+    the mid level 0.5 (silence maps there, wav.py:148-151), here [0.25, 0.75) (include/sushi_hip.h,
+    sushi_hip_match_batch)."""
     from oracle import oracle as O
     O.build()
     M = max(1, min(L, int(round(frac * L))))
@@ -497,9 +502,12 @@ def test_random_shapes_property(seed, L, frac, u8, path):
     if u8:
         dst = rng.integers(0, 256, L + 5, dtype=np.uint8)
         src = rng.integers(0, 256, M + 3, dtype=np.uint8)
+    elif path == "fft":
+        dst = (rng.random(L + 5) * scale).astype(np.float32)
+        src = (rng.random(M + 3) * scale).astype(np.float32)
     else:
-        dst = rng.random(L + 5, dtype=np.float32)
-        src = rng.random(M + 3, dtype=np.float32)
+        dst = (0.25 + 0.5 * rng.random(L + 5)).astype(np.float32)
+        src = (0.25 + 0.5 * rng.random(M + 3)).astype(np.float32)
     if M >= 8 and L - M >= 1:
         p = int(rng.integers(0, L - M + 1))                  # plant a noisy copy somewhere
         src[1:1 + M] = dst[2 + p:2 + p + M]

@@ -24,13 +24,13 @@ def test_library_builds_and_exports_all_declared_symbols():
 
 def test_host_only_entry_points():
     L = _native.lib()
-    assert L.sushi_hip_abi_version() == 3
+    assert L.sushi_hip_abi_version() == 4
     assert L.sushi_hip_strerror(0) == b"ok" and b"invalid" in L.sushi_hip_strerror(-1)
     assert _native.variant_tiles() == [1024, 4096, 16384]
     assert L.sushi_hip_variant_tile_positions(99) == -1
     assert L.sushi_hip_centre(_native.U8) == 128.0 and L.sushi_hip_centre(_native.F32) == 0.5
-    assert L.sushi_hip_prepare_base_bytes(4096) == 3 * 2 * 8          # nb = 1: bases of block 0 and of sample n, three sums
-    assert L.sushi_hip_prepare_base_bytes(4097) == 3 * 3 * 8
+    assert L.sushi_hip_prepare_base_bytes(4096) == 2 * 2 * 8          # nb = 1: bases of block 0 and of sample n, two sums
+    assert L.sushi_hip_prepare_base_bytes(4097) == 2 * 3 * 8
     # argument validation happens before any HIP call
     assert L.sushi_hip_prepare_stream(None, 1, 10, None, None, None, None, None, 0, None) == -1
     assert L.sushi_hip_match_batch(None, None, None, 0, None, None, None, 0, 0.5, 0, None, 0, 0, 0,
@@ -55,8 +55,8 @@ def test_host_only_entry_points():
         assert (int(vp[0]), int(vs[0])) == (pairs.value, segs.value)
     assert L.sushi_hip_fft_workspace_bytes(1, 1, 1) == 65536 + 65536 + 3 * 256
     assert L.sushi_hip_fft_workspace_bytes(176555, 9379, 1000) > L.sushi_hip_fft_workspace_bytes(176555, 9379, 1)
-    assert L.sushi_hip_prepare_spectra(None, 10, 0.5, None, 0, None) == -1
-    assert L.sushi_hip_match_batch_fft(None, None, None, 0, None, None, None, None, None, None, 0, 0.5, 0, None, None,
+    assert L.sushi_hip_prepare_spectra(None, 1, 10, None, 0, None) == -1
+    assert L.sushi_hip_match_batch_fft(None, None, None, 0, None, None, None, None, None, None, 0, None, None, 1, 0, None, None,
                                        0, 2e-5, None, 0, None, None, None, None, None, None) == -1
     # the inverse-transform schedule is a permutation of each sub-batch's pairs
     win = np.array([100000, 140000, 190000, 300000], np.int64)       # equal shapes: with the smallest workspace
