@@ -257,7 +257,10 @@ def main():
                         "direct_form_equivalent_TFLOPs": flops_launch / (kernel_ms * 1e-3) / 1e12,
                         "fft_pairs": batch.fft_pairs, "fft_segments": batch.fft_segs,
                         "workspace_bytes": batch.ws_bytes, "delta": batch.delta,
-                        "searches_finished_by_direct_kernel": batch.fallback_count()}
+                        "searches_finished_by_direct_kernel": batch.fallback_count(),
+                        # what a bare streaming kernel reaches on this part (tools/ubench/hbm_bw.hip,
+                        # profiles/r01/hbm_bw.jsonl): the practical ceiling under the 8 TB/s peak
+                        "stream_ceiling_GBps": {"read": 6300.0, "write": 5300.0, "copy": 5500.0}}
         else:
             achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
             hbm_achieved = batch.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
