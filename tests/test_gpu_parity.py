@@ -299,6 +299,25 @@ def test_full_size_windows_properties(oracle, hip_path):
         assert _score_ok(diffs[k], rdiff), (diffs[k], rdiff)
 
 
+@pytest.mark.parametrize("variant", PATHS)
+def test_known_answers_by_hand(variant):
+    """The hand-worked vectors of tests/test_oracle.py::test_known_answers_by_hand, through the C ABI."""
+    from math import sqrt
+    cases = [
+        (np.array([1, 2, 3, 4], np.float32), np.array([2, 3], np.float32), 1, 0.0),
+        (np.array([3, 0, 4, 0, 3], np.float32), np.array([0, 5], np.float32), 1, 1.0 / 20.0),
+        (np.array([10, 20, 30, 40, 50], np.uint8), np.array([20, 30, 40], np.uint8), 1, 0.0),
+        # windows [50 40 30]: 2000 / sqrt(5000 * 1400) = 0.756; [40 30 20]: 1100 / sqrt(2900 * 1400) = 0.546;
+        # [30 20 10]: 800 / 1400 = 0.571
+        (np.array([50, 40, 30, 20, 10], np.uint8), np.array([10, 20, 30], np.uint8), 1,
+         1100.0 / sqrt(2900.0 * 1400.0)),
+    ]
+    for img, t, want_idx, want_score in cases:
+        idx, score = _run_batch(img, t, [0], [len(t)], [0], [len(img) - len(t) + 1], variant)
+        assert int(idx[0]) == want_idx
+        assert abs(float(score[0]) - want_score) <= 6e-8 + 1e-7 * want_score
+
+
 # ----------------------------------------------------------------------------------------------
 # FFT path specifics
 # ----------------------------------------------------------------------------------------------

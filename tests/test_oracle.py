@@ -132,3 +132,33 @@ def test_golden_index_arithmetic(oracle, golden_index):
     assert n_ok > 1000
     for c in golden_index["clip"]:
         assert oracle.clip(c["v"], c["lo"], c["hi"]) == c["out"]
+
+
+def test_known_answers_by_hand(oracle):
+    """Known answers worked out by hand from OpenCV's documented TM_SQDIFF_NORMED formula
+    R(x) = sum (T(x') - I(x + x'))^2 / sqrt(sum T(x')^2 * sum I(x + x')^2), exact rationals / surds:
+      I = [1 2 3 4], T = [2 3]   -> numerators 2, 0, 2; denominators sqrt(13*5), 13, sqrt(13*25)
+      I = [3 0 4 0 3], T = [0 5] -> window [0 4] gives 1/20 (numerator 1, denominator sqrt(25*16)),
+                                    the other windows' numerators reach their denominators: clamped to 1
+      uint8 I = [10 20 30 40 50], T = [20 30 40] -> 300/sqrt(2900*1400), 0, 300/sqrt(2900*5000)."""
+    from fractions import Fraction
+    from math import sqrt
+    img = np.array([1, 2, 3, 4], np.float32)
+    t = np.array([2, 3], np.float32)
+    got = oracle.match_template_direct(img, t)[0]
+    exp = [2 / sqrt(65.0), 0.0, 2 / sqrt(325.0)]
+    np.testing.assert_allclose(got, np.array(exp, np.float32), rtol=0, atol=6e-8)
+    assert oracle.argmin_first(got) == 1
+    img = np.array([3, 0, 4, 0, 3], np.float32)
+    t = np.array([0, 5], np.float32)
+    got = oracle.match_template_direct(img, t)[0]
+    # windows [3 0]: num 9+25=34 >= den 15 -> 1; [0 4]: num 1, den 20; [4 0]: num 16+25=41 >= 20 -> 1; [0 3]: 4/15
+    exp = [1.0, float(Fraction(1, 20)), 1.0, float(Fraction(4, 15))]
+    np.testing.assert_allclose(got, np.array(exp, np.float32), rtol=0, atol=6e-8)
+    assert oracle.argmin_first(got) == 1
+    img = np.array([10, 20, 30, 40, 50], np.uint8)
+    t = np.array([20, 30, 40], np.uint8)
+    for fn in (oracle.match_template_direct, oracle.match_template_fft):
+        got = fn(img, t)[0]
+        exp = np.array([300 / sqrt(2900.0 * 1400.0), 0.0, 300 / sqrt(2900.0 * 5000.0)], np.float32)
+        assert (got == exp).all()                           # integer sums, correctly rounded quotient
