@@ -159,10 +159,12 @@ SUSHI_HIP_API int sushi_hip_prepare_spectra(const void* raw_dev, int dtype, int6
  *   searches_host     : the same n_search descriptors in host memory (read during the call only);
  *                       first_tile must be laid out for variant sushi_hip_variant_count()-1,
  *                       first_pair / first_seg as running sums of sushi_hip_fft_layout()
- *   delta             : score margin, > 2x the error of the f32 FFT scores.  The FFT stage works on the
- *                       UNCENTRED samples, so its error in score units is bounded by a few float32 epsilons
- *                       whatever the data (|d corr| <~ eps * |T| * |I| = eps * the score's denominator);
- *                       2e-5 leaves a margin of ~10x (measured: sushi_hip_fft_last_errors)
+ *   delta             : score margin, > 2x the error of the f32 FFT scores.  |d corr| <~ eps * |T| * |B|, B the
+ *                       2*hop-sample blocks the window lies in: in score units a few float32 epsilons times
+ *                       |B| / |window|.  For WavStream data (samples in [0,1] around the mid level) that ratio is
+ *                       <= 2 * sqrt(max(1, 2*hop / tmpl_len)); patterns shorter than 2048 samples, where it
+ *                       grows, are finished by the direct kernel whatever the FFT stage says.  2e-5 leaves a
+ *                       margin of ~8x on BASELINE-shaped batches (measured per search: keys_ws_dev below)
  *   ws_dev / ws_bytes : scratch, >= sushi_hip_fft_workspace_bytes(pairs, segments, 1) of the largest search
  *   keys_ws_dev       : uint64[2 * n_search] scratch
  *   pair_order_dev    : int32[total pairs] from sushi_hip_fft_pair_order for the SAME ws_bytes, or NULL
@@ -170,7 +172,8 @@ SUSHI_HIP_API int sushi_hip_prepare_spectra(const void* raw_dev, int dtype, int6
  *                       of search k's result position (0 for searches finished by the direct kernel): the
  *                       measured error of the ranking stage, to be compared with delta / 2
  *   flags_dev         : int32[2 * n_search + 2] scratch; on completion flags[k] = 1 if search k had too
- *                       many near-ties and was finished by the direct kernel, flags[n_search] = how many */
+ *                       many near-ties and was finished by the direct kernel (and so carries
+ *                       sushi_hip_match_batch's accuracy contract), flags[n_search] = how many */
 SUSHI_HIP_API int sushi_hip_match_batch_fft(const float* dst_xc_dev, const double* dst_s1_dev, const double* dst_s2_dev, int64_t dst_len,
                               const float* dst_urel_dev, const double* dst_base_dev, const void* dst_spec_dev,
                               const float* src_xc_dev, const double* src_s1_dev, const double* src_s2_dev, int64_t src_len,

@@ -50,6 +50,9 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise NativeError("libsushi_hip.so is not built (%s); run `python -m sushi_amd.build` -- "
                           "there is no CPU fallback for the matching path" % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime (same SONAME as /opt/rocm's).  Whichever is mapped first serves the
+    # whole process, and torch cannot see the GPU through the other one: torch first, then our library.
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, i64, ci, dbl, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
     L.sushi_hip_abi_version.restype = ci

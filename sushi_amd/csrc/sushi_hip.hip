@@ -294,7 +294,7 @@ void refine_kernel(RefineArgs a) {
     const int s_idx = a.first_search + blockIdx.x;
     const SushiHipSearch sd = a.searches[s_idx];
     const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
-    if (tid == 0) { cnt = 0; ovf = 0; }
+    if (tid == 0) { cnt = 0; ovf = sd.tmpl_len < FFT_MIN_TMPL ? 1 : 0; }      // short patterns: the direct kernel's
     __syncthreads();
     const float thr = key_score(a.gkeys[s_idx]) + a.delta;
     const unsigned long long* __restrict__ c = a.cand + (size_t)(sd.first_pair - a.sub_first_pair) * (FFT_CAND + 1);
@@ -451,15 +451,26 @@ __global__ __launch_bounds__(PB_THREADS)
 void final_scan_kernel(const T* __restrict__ raw, int64_t n, const double* __restrict__ bs1,
                        const double* __restrict__ bs2, double* __restrict__ s1, double* __restrict__ s2,
                        float* __restrict__ urel) {
+    // A thread scans PB_PER_THREAD consecutive samples, but global memory is touched a workgroup-wide row at a
+    // time: samples come in and prefix values go out through a padded LDS tile (index + index / 16: the
+    // 16-element runs of neighbouring threads start in different banks).
+    __shared__ double tile[PB + PB / PB_PER_THREAD];
     __shared__ double w1[PB_THREADS / 64], w2[PB_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t base = (int64_t)blockIdx.x * PB + (int64_t)tid * PB_PER_THREAD;  // 16 consecutive samples
+    const int64_t blk = (int64_t)blockIdx.x * PB;
+    auto pad = [](const int i) { return i + i / PB_PER_THREAD; };
+#pragma unroll
+    for (int k = 0; k < PB_PER_THREAD; ++k) {
+        const int i = k * PB_THREADS + tid;                              // coalesced
+        const int64_t e = blk + i;
+        tile[pad(i)] = e < n ? (double)raw[e] : 0.0;
+    }
+    __syncthreads();
     double v[PB_PER_THREAD];
     double l1 = 0.0, l2 = 0.0;
 #pragma unroll
     for (int k = 0; k < PB_PER_THREAD; ++k) {
-        const int64_t e = base + k;
-        v[k] = e < n ? (double)raw[e] : 0.0;
+        v[k] = tile[pad(tid * PB_PER_THREAD + k)];
         l1 += v[k];
         l2 += v[k] * v[k];
     }
@@ -467,24 +478,50 @@ void final_scan_kernel(const T* __restrict__ raw, int64_t n, const double* __res
     double e1 = wave_excl_scan(l1, &t1);
     double e2 = wave_excl_scan(l2, &t2);
     if (lane == 0) { w1[wv] = t1; w2[wv] = t2; }
-    __syncthreads();
-    for (int w = 0; w < wv; ++w) { e1 += w1[w]; e2 += w2[w]; }        // prefix inside the block, before sample `base`
-    const double o1 = bs1[blockIdx.x], o2 = bs2[blockIdx.x];          // block bases
+    __syncthreads();                                                     // also: everyone has read its samples
+    for (int w = 0; w < wv; ++w) { e1 += w1[w]; e2 += w2[w]; }           // prefix inside the block, before the thread's run
+    const double o1 = bs1[blockIdx.x], o2 = bs2[blockIdx.x];             // block bases
     if (blockIdx.x == 0 && tid == 0) {
         s1[0] = 0.0; s2[0] = 0.0;
-        if (n % PB == 0) urel[n] = 0.f;                               // sample n opens a block of its own: base2[n / PB] = total
+        if (n % PB == 0) urel[n] = 0.f;                                  // sample n opens a block of its own: base2[n / PB] = total
     }
+    // s1[e + 1], s2[e + 1] (inclusive sums) and urel[e] (exclusive, relative to the block), one array at a time
+    {
+        double r = e1;
+#pragma unroll
+        for (int k = 0; k < PB_PER_THREAD; ++k) { r += v[k]; tile[pad(tid * PB_PER_THREAD + k)] = o1 + r; }
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < PB_PER_THREAD; ++k) {
-        const int64_t e = base + k;
-        if (e < n) {
-            urel[e] = (float)e2;
-            e1 += v[k];
-            e2 += v[k] * v[k];
-            s1[e + 1] = o1 + e1;
-            s2[e + 1] = o2 + e2;
-            if (e + 1 == n && (n % PB) != 0) urel[n] = (float)e2;
-        }
+        const int i = k * PB_THREADS + tid;
+        if (blk + i < n) s1[blk + i + 1] = tile[pad(i)];
+    }
+    __syncthreads();
+    {
+        double r = e2;
+#pragma unroll
+        for (int k = 0; k < PB_PER_THREAD; ++k) { r += v[k] * v[k]; tile[pad(tid * PB_PER_THREAD + k)] = o2 + r; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PB_PER_THREAD; ++k) {
+        const int i = k * PB_THREADS + tid;
+        if (blk + i < n) s2[blk + i + 1] = tile[pad(i)];
+    }
+    __syncthreads();
+    float* __restrict__ ftile = reinterpret_cast<float*>(tile);
+    {
+        double r = e2;
+#pragma unroll
+        for (int k = 0; k < PB_PER_THREAD; ++k) { ftile[pad(tid * PB_PER_THREAD + k)] = (float)r; r += v[k] * v[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PB_PER_THREAD; ++k) {
+        const int i = k * PB_THREADS + tid;
+        // e == n inside this block (n % PB != 0): samples past the end are zeros, so the running sum there is the total
+        if (blk + i <= n) urel[blk + i] = ftile[pad(i)];
     }
 }
 
