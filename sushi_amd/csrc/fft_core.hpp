@@ -234,6 +234,89 @@ __device__ __forceinline__ void fft8192(cpx* v, int tid, cpx* lds, const Twiddle
     pass_compute<16, 16, 512, DIR>(v, tw.p4);
 }
 
+#endif  // __HIPCC__
+
+// The same transform with the real and imaginary parts exchanged one after the other through `lds`, a buffer
+// of SPLIT_LDS_FLOATS floats.  After a part's loads every thread's registers hold the new part next to the OTHER
+// part of the old element set, which is then stored in turn.
+// A 4-byte element wants other paddings than an 8-byte one (32 banks x 4 bytes, 32 lanes per access), and every
+// exchange is free to lay the buffer out its own way as long as its stores and loads agree:
+//   after pass 1 : pos(e) = e + (e >> 5)        stores 16 tid + u -> 16 tid + (tid >> 1) + u   (lane stride 16.5: all banks)
+//   after pass 2 : pos(e) = e + 8 (e >> 6)      stores 64 a + b + 8 t (tid = 8 a + b) -> 72 a + b + 8 t  (8 (a & 3) + b: all banks)
+//   after pass 3 : pos(e) = e                   stores 512 w + l + 64 t: lanes are unit stride as they are
+// and the loads, unit stride over the lanes with a constant multiple of 512 between a thread's inputs, are
+// conflict free in all three (a 32-lane group never straddles a padding step).  Offsets stay immediates.
+constexpr int SPLIT_LDS_FLOATS = N + N / 8;
+
+template <int IM> SUSHI_HD float part_of(const cpx& c) { return IM ? c.y : c.x; }
+template <int IM> SUSHI_HD void set_part(cpx& c, const float e) { if (IM) c.y = e; else c.x = e; }
+
+template <int EX, int IM>
+SUSHI_HD void split_store(const cpx* v, int tid, float* lds) {
+    if (EX == 1) {                                   // pass 1 outputs: the thread's 16 contiguous elements
+        float* out = lds + 16 * tid + (tid >> 1);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) out[u] = part_of<IM>(v[u]);
+    } else if (EX == 2) {                            // R = 8, NS = 8: butterflies j = tid, tid + 512
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = tid + 512 * b;
+            float* out = lds + 72 * (j >> 3) + (j & 7);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) out[8 * t] = part_of<IM>(v[b * 8 + t]);
+        }
+    } else {                                         // R = 8, NS = 64: base = 8 (j - k) + k, k = j & 63
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = tid + 512 * b;
+            float* out = lds + 8 * (j & ~63) + (j & 63);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) out[64 * t] = part_of<IM>(v[b * 8 + t]);
+        }
+    }
+}
+
+// inputs of the next pass (radix R): x[j + t N/R], j = tid (+ 512)
+template <int EX, int R, int IM>
+SUSHI_HD void split_load(cpx* v, int tid, const float* lds) {
+    constexpr int NB = 16 / R;
+    constexpr int S = N / R;                         // 1024 or 512
+    constexpr int STEP = EX == 1 ? S + (S >> 5) : (EX == 2 ? S + 8 * (S >> 6) : S);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = tid + 512 * b;
+        const float* in = lds + (EX == 1 ? j + (j >> 5) : (EX == 2 ? j + 8 * (j >> 6) : j));
+#pragma unroll
+        for (int t = 0; t < R; ++t) set_part<IM>(v[b * R + t], in[t * STEP]);
+    }
+}
+
+#ifdef __HIPCC__
+template <int EX, int R_NEXT, class Hook = NoHook>
+__device__ __forceinline__ void exchange_split(cpx* v, int tid, float* lds, Hook before_last_barrier = Hook()) {
+    split_store<EX, 0>(v, tid, lds);
+    SUSHI_FFT_BARRIER();
+    split_load<EX, R_NEXT, 0>(v, tid, lds);
+    SUSHI_FFT_BARRIER();
+    split_store<EX, 1>(v, tid, lds);
+    before_last_barrier();
+    SUSHI_FFT_BARRIER();
+    split_load<EX, R_NEXT, 1>(v, tid, lds);
+}
+
+template <int DIR, class Hook = NoHook>
+__device__ __forceinline__ void fft8192_split(cpx* v, int tid, float* lds, const Twiddles tw, Hook before_last_pass = Hook()) {
+    pass_compute<16, 8, 1, DIR>(v, cpx{1.f, 0.f});
+    exchange_split<1, 8>(v, tid, lds);
+    pass_compute<16, 8, 8, DIR>(v, tw.p2);
+    SUSHI_FFT_BARRIER();
+    exchange_split<2, 8>(v, tid, lds);
+    pass_compute<16, 8, 64, DIR>(v, tw.p3);
+    SUSHI_FFT_BARRIER();
+    exchange_split<3, 16>(v, tid, lds, before_last_pass);
+    pass_compute<16, 16, 512, DIR>(v, tw.p4);
+}
+
 // The same transform by 256 threads x 32 points (Shape<256>).
 template <int DIR, class Hook = NoHook>
 __device__ __forceinline__ void fft8192_w256(cpx* v, int tid, cpx* lds, const Twiddles tw, Hook before_last_pass = Hook()) {

@@ -32,7 +32,7 @@ static void ref_fft(std::vector<cd>& a, int dir) {   // iterative radix-2, float
     }
 }
 
-template <int NTS, int DIR>
+template <int NTS, int DIR, bool SPLIT = false>
 static double run(const std::vector<cpx>& tw, unsigned seed) {
     constexpr int P = N / NTS;
     std::vector<cpx> x(N);
@@ -49,7 +49,23 @@ static double run(const std::vector<cpx>& tw, unsigned seed) {
         for (int q = 0; q < P; ++q) regs[(size_t)tid * P + q] = x[in_index_t<NTS>(tid, q)];
 #define ALL(stmt) for (int tid = 0; tid < NTS; ++tid) { cpx* v = &regs[(size_t)tid * P]; \
         const Twiddles t = load_twiddles<NTS, DIR>(tid, tw.data()); (void)t; stmt; }
-    if (NTS == 512) {
+    if (NTS == 512 && SPLIT) {
+        // fft8192_split: real parts, then imaginary parts, through a buffer of LDS_ELEMS floats
+        std::vector<float> fl(SPLIT_LDS_FLOATS);
+#define XCHG(EX, RN) \
+        ALL((split_store<EX, 0>(v, tid, fl.data()))) \
+        ALL((split_load<EX, RN, 0>(v, tid, fl.data()))) \
+        ALL((split_store<EX, 1>(v, tid, fl.data()))) \
+        ALL((split_load<EX, RN, 1>(v, tid, fl.data())))
+        ALL((pass_compute<16, 8, 1, DIR>(v, cpx{1.f, 0.f})))
+        XCHG(1, 8)
+        ALL((pass_compute<16, 8, 8, DIR>(v, t.p2)))
+        XCHG(2, 8)
+        ALL((pass_compute<16, 8, 64, DIR>(v, t.p3)))
+        XCHG(3, 16)
+        ALL((pass_compute<16, 16, 512, DIR>(v, t.p4)))
+#undef XCHG
+    } else if (NTS == 512) {
         ALL((pass_compute<16, 8, 1, DIR>(v, cpx{1.f, 0.f}), pass_store<512, 8, 1, true>(v, tid, lds.data())))
         ALL((pass_load<512, 8>(v, tid, lds.data()), pass_compute<16, 8, 8, DIR>(v, t.p2)))
         ALL((pass_store<512, 8, 8, false>(v, tid, lds.data())))
@@ -81,6 +97,7 @@ int main() {
     }
     const double f = run<512, -1>(tw, 1), b = run<512, 1>(tw, 2);
     const double f2 = run<256, -1>(tw, 3), b2 = run<256, 1>(tw, 4);
-    printf("%.3e %.3e %.3e %.3e\n", f, b, f2, b2);
-    return (f < 1e-6 && b < 1e-6 && f2 < 1e-6 && b2 < 1e-6) ? 0 : 1;
+    const double f3 = run<512, -1, true>(tw, 5), b3 = run<512, 1, true>(tw, 6);
+    printf("%.3e %.3e %.3e %.3e %.3e %.3e\n", f, b, f2, b2, f3, b3);
+    return (f < 1e-6 && b < 1e-6 && f2 < 1e-6 && b2 < 1e-6 && f3 < 1e-6 && b3 < 1e-6) ? 0 : 1;
 }

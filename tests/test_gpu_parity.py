@@ -523,7 +523,7 @@ def test_random_shapes_property(seed, L, frac, u8, path, scale):
     if u8:
         dst = rng.integers(0, 256, L + 5, dtype=np.uint8)
         src = rng.integers(0, 256, M + 3, dtype=np.uint8)
-    elif path == "fft":
+    elif path == "fft" and M >= 2048:      # shorter patterns are the direct kernel's (FFT_MIN_TMPL)
         dst = (rng.random(L + 5) * scale).astype(np.float32)
         src = (rng.random(M + 3) * scale).astype(np.float32)
     else:

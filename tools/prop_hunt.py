@@ -19,6 +19,8 @@ def main():
     for c in range(n_cases):
         seed = int(master.integers(0, 2 ** 31 - 1))
         L = int(master.integers(1, 30001)) if master.random() < 0.7 else int(master.integers(1, 200))
+        if master.random() < 0.3:
+            L = int(master.integers(2048, 60000))
         frac = float(master.random()) if master.random() < 0.8 else float(master.choice([0.0, 1.0]))
         u8 = bool(master.integers(0, 2))
         path = [0, 2, "fft"][int(master.integers(0, 3))]
@@ -28,7 +30,7 @@ def main():
         if u8:
             dst = rng.integers(0, 256, L + 5, dtype=np.uint8)
             src = rng.integers(0, 256, M + 3, dtype=np.uint8)
-        elif path == "fft":
+        elif path == "fft" and M >= 2048:      # shorter patterns are the direct kernel's (FFT_MIN_TMPL)
             dst = (rng.random(L + 5) * scale).astype(np.float32)
             src = (rng.random(M + 3) * scale).astype(np.float32)
         else:
