@@ -92,13 +92,18 @@ SUSHI_MAC_HD void mac_chunk(const int npairs, const int zoff, const c2 (&tt)[SMA
 #pragma unroll
     for (int r = 0; r < ZR; ++r) zbuf[r] = load_z(zoff + r);
     const int total = STEP * (npairs - 1) + SMAX;               // block spectra this chunk consumes
-    for (int jb = 0; jb < total; jb += SMAX) {
-        // stores of this group are pairs (jb + STEP - SMAX)/STEP .. (jb + SMAX - STEP)/STEP: all exist in the interior
-        if (jb >= SMAX && (jb + SMAX - STEP) / STEP < npairs)
-            mac_group<SMAX, STEP, false, ACCUM>(jb, npairs, zoff, tt, acc, zbuf, load_z, load_y, store_y);
-        else
-            mac_group<SMAX, STEP, true, ACCUM>(jb, npairs, zoff, tt, acc, zbuf, load_z, load_y, store_y);
-    }
+    // The stores of group jb are pairs (jb + STEP - SMAX)/STEP .. (jb + SMAX - STEP)/STEP: all of them exist for
+    // SMAX <= jb < interior_end.  Three loops rather than one with a branch in it: the interior loop then has a
+    // single body, and the wait counts the compiler derives at its back edge are those of that body (with the
+    // checked variant as a second path through the loop it falls back to a full drain at every group).
+    const int interior_end = STEP * npairs - SMAX + STEP;
+    int jb = 0;
+    mac_group<SMAX, STEP, true, ACCUM>(jb, npairs, zoff, tt, acc, zbuf, load_z, load_y, store_y);
+    jb += SMAX;
+    for (; jb < interior_end; jb += SMAX)
+        mac_group<SMAX, STEP, false, ACCUM>(jb, npairs, zoff, tt, acc, zbuf, load_z, load_y, store_y);
+    for (; jb < total; jb += SMAX)
+        mac_group<SMAX, STEP, true, ACCUM>(jb, npairs, zoff, tt, acc, zbuf, load_z, load_y, store_y);
 }
 
 // load_t(s)  -> Tt_s           (0 <= s < n_seg)
