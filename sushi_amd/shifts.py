@@ -35,14 +35,16 @@ SMALL_WINDOW = 1.5        # sushi.py:410
 
 
 class ScriptEvent(object):
-    """The part of subs.ScriptEventBase (subs.py:14-80) calculate_shifts touches: a time span, a
-    shift/diff pair, and links to another event whose shift it follows."""
+    """The part of subs.ScriptEventBase (subs.py:14-80) that calculate_shifts and the grouping code
+    (sushi_amd/grouping.py) touch: a time span, a shift/diff pair, and links to another event whose shift
+    it follows."""
 
-    def __init__(self, start, end, source_index=0, text=u''):
+    def __init__(self, start, end, source_index=0, text=u'', is_comment=False):
         self.source_index = source_index
         self.start = start
         self.end = end
         self.text = text
+        self.is_comment = is_comment      # subs.py: AssEvent / SrtEvent attribute read by prepare_search_groups
         self._shift = 0
         self._diff = 1
         self._linked_event = None
@@ -74,6 +76,14 @@ class ScriptEvent(object):
     def link_event(self, other):
         assert other.get_link_chain_end() is not self, 'Circular link detected'
         self._linked_event = other
+
+    def resolve_link(self):
+        assert self.linked, 'Cannot resolve unlinked events'
+        self._shift, self._diff = self._linked_event.shift, self._linked_event.diff
+        self._linked_event = None
+
+    def __str__(self):
+        return u'{0}-{1} {2}'.format(format_time(self.start), format_time(self.end), self.text)
 
 
 def _span_state(group, shift=None, diff=None):

@@ -172,3 +172,72 @@ def test_lookahead_grows_while_the_shift_holds(oracle):
     assert ra == rb
     assert len(events) >= 40 and proxy.launches <= 6           # 4 + 8 + 16 + 32 instead of n / 4
     assert proxy.lookahead > 4
+
+
+def _pipeline(src, dst, events, chapters, window=10, max_window=30, rewind=5):
+    """sushi.run's audio path (sushi.py:624-626, 664-670, 682-704): search groups, shifts, grouping."""
+    from sushi_amd import grouping
+    groups = grouping.prepare_search_groups(events, src.duration_seconds, chapters, 1001.0 / 24000.0 * 10, 2)
+    calculate_shifts_batched(src, dst, groups, window, max_window, rewind)
+    return grouping.group_shifts(events, chapters, smooth_radius=3)
+
+
+def _config4_events(rng, seconds, n):
+    """A script with what prepare_search_groups has to deal with: dialogue, a comment, a zero-length line,
+    an exact duplicate and a run of short typesetting lines."""
+    starts = np.sort(rng.uniform(8.0, seconds - 12.0, n))
+    events = []
+    for s in starts:
+        if events and s < events[-1].end + 0.05:
+            continue
+        events.append(ScriptEvent(float(s), float(s + rng.uniform(1.0, 3.0))))
+    events.insert(5, ScriptEvent(events[5].start, events[5].end))                      # duplicate of the next line
+    events.insert(11, ScriptEvent(events[11].start - 0.01, events[11].start - 0.01))   # zero length
+    events.insert(17, ScriptEvent(events[17].start - 0.02, events[17].start + 1.0, is_comment=True))
+    t0 = events[23].end + 0.01
+    for k in range(4):                                                                  # typesetting: 0.3 s lines 0.1 s apart
+        events.insert(24 + k, ScriptEvent(t0 + 0.4 * k, t0 + 0.4 * k + 0.3))
+    events.sort(key=lambda e: e.start)
+    return events
+
+
+def test_config4_pipeline_on_cpu_recovers_chapter_offsets(oracle):
+    """BASELINE configs[3] end to end with the oracle as the matching backend: every event ends up within one
+    sample of its chapter's planted offset, one group per chapter."""
+    OracleBackedStream.oracle = oracle
+    pieces = [(0.0, -3.0), (50.0, 1.25), (100.0, 6.5)]
+    src, dst, _, true_off = _scenario(4000, 150, pieces, 10, "uint8", OracleBackedStream, seed=33)
+    events = _config4_events(np.random.default_rng(5), 150, 45)
+    chapters = [t for t, _ in pieces]
+    groups = _pipeline(src, dst, events, chapters)
+    assert len(groups) == len(pieces)
+    for e in events:
+        if true_off(e.start) == true_off(e.end):                       # a line across a chapter mark follows its END (sushi.py:137)
+            assert abs(e.shift - true_off(e.start)) <= 1.5 / 4000, (e.start, e.shift)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sample_type", ["uint8", "float32"])
+def test_config4_pipeline_on_gpu_matches_oracle_run(oracle, sample_type):
+    """BASELINE configs[3] end to end: prepare_search_groups -> calculate_shifts (batched, HIP path) -> the
+    --grouping block, against the same pipeline with the oracle doing the matching, and against the planted
+    per-chapter offsets (five chapters, -30 ... +30 s scaled to the test's stream)."""
+    OracleBackedStream.oracle = oracle
+    pieces = [(0.0, -6.0), (60.0, -2.4), (120.0, 0.6), (180.0, 3.4), (240.0, 6.0)]
+    src, dst, _, true_off = _scenario(12000, 300, pieces, 10, sample_type, WavStream, seed=41)
+    osrc = OracleBackedStream.__new__(OracleBackedStream); osrc.__dict__.update(src.__dict__)
+    odst = OracleBackedStream.__new__(OracleBackedStream); odst.__dict__.update(dst.__dict__)
+    ev_gpu = _config4_events(np.random.default_rng(9), 300, 70)
+    ev_cpu = [ScriptEvent(e.start, e.end, is_comment=e.is_comment) for e in ev_gpu]
+    chapters = [t for t, _ in pieces]
+    g_gpu = _pipeline(src, dst, ev_gpu, chapters)
+    g_cpu = _pipeline(osrc, odst, ev_cpu, chapters)
+    assert [len(g) for g in g_gpu] == [len(g) for g in g_cpu] and len(g_gpu) == len(pieces)
+    for a, b in zip(ev_gpu, ev_cpu):
+        assert a.linked == b.linked
+        if sample_type == "uint8":
+            assert a.shift == b.shift                                   # same positions, same scores: same averages
+        else:
+            assert abs(a.shift - b.shift) <= 1e-6                       # score-weighted averages of identical positions
+        if true_off(a.start) == true_off(a.end):                       # a line across a chapter mark follows its END (sushi.py:137)
+            assert abs(a.shift - true_off(a.start)) <= 1.5 / 12000, (a.start, a.shift)
