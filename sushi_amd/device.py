@@ -194,9 +194,11 @@ class SearchBatch(object):
             _native.check(L.sushi_hip_fft_pair_order(desc.ctypes.data, n, self.ws_bytes, self.host_order.ctypes.data,
                                                      self.fft_pairs), "sushi_hip_fft_pair_order")
         self.host_desc = desc
-        # algorithmic work of this batch: 2*P*M flop, 4*(P+M-1)+4*M+8 bytes per search
+        # algorithmic work of this batch: 2*P*M flop; every search and pattern sample read
+        # once (4 bytes for float32 streams, 1 for uint8) and 8 bytes out per search
         self.flops = float((2.0 * n_pos.astype(np.float64) * tmpl_len.astype(np.float64)).sum())
-        self.algorithmic_bytes = float((4.0 * (n_pos + tmpl_len - 1) + 4.0 * tmpl_len + 8.0).sum())
+        width = float(dst.dtype.itemsize)
+        self.algorithmic_bytes = float((width * (n_pos + tmpl_len - 1) + width * tmpl_len + 8.0).sum())
         dev = dst.device
         with torch.cuda.device(dev):
             self.desc = torch.from_numpy(desc.view(np.uint8).reshape(-1)).to(dev)
