@@ -17,6 +17,9 @@
 // one LDS buffer, padded by one element per 16 (pad(e) = e + e/16) so that the transposing stores are
 // (nearly) bank-conflict free; all pad() arithmetic is folded into per-thread bases plus immediates.
 //
+// The inverse transforms of the hot path use fft8192_split below: real parts, then imaginary parts, through a
+// float buffer of half the size with its own conflict-free layout per exchange.
+//
 // Everything here is written against explicit (tid, lds) arguments so that tests/host_fft_check.cpp
 // can run the same code on the CPU, one "thread" at a time, with the barriers replaced by loops.
 #ifndef SUSHI_FFT_CORE_HPP
