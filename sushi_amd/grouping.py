@@ -52,7 +52,9 @@ def detect_groups(events):
             groups.append([])
         groups[-1].append(e)
     if not groups:
-        raise StopIteration            # the reference's next() on an empty iterator (sushi.py:122)
+        # the reference lets next() on the empty iterator raise StopIteration here (sushi.py:122); an exception of
+        # our own cannot be swallowed by an enclosing for loop or generator
+        raise SushiError('No events to group')
     return groups
 
 
