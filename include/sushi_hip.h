@@ -18,7 +18,8 @@
  *   sushi_hip_match_batch_fft  the same contract as sushi_hip_match_batch through overlap-save FFT
  *                              (what cv2's crossCorr does): f32 FFT scores for every position, then
  *                              the exact float64 evaluation of every position within `delta` of the
- *                              minimum; searches with too many near-ties are finished by the direct kernel.
+ *                              minimum; searches with too many near-ties are finished by a kernel that evaluates
+ *                              every position (float64 for float32 streams, the MFMA kernel for uint8).
  *
  * Conventions: extern "C", plain pointers and sizes, no C++ or torch types.  Every pointer
  * named *_dev is a device (HBM) pointer owned by the caller for the duration of the call's
@@ -163,17 +164,18 @@ SUSHI_HIP_API int sushi_hip_prepare_spectra(const void* raw_dev, int dtype, int6
  *                       2*hop-sample blocks the window lies in: in score units a few float32 epsilons times
  *                       |B| / |window|.  For WavStream data (samples in [0,1] around the mid level) that ratio is
  *                       <= 2 * sqrt(max(1, 2*hop / tmpl_len)); patterns shorter than 2048 samples, where it
- *                       grows, are finished by the direct kernel whatever the FFT stage says.  2e-5 leaves a
+ *                       grows, are finished by the fallback kernel (flags_dev) whatever the FFT stage says.  2e-5 leaves a
  *                       margin of ~8x on BASELINE-shaped batches (measured per search: keys_ws_dev below)
  *   ws_dev / ws_bytes : scratch, >= sushi_hip_fft_workspace_bytes(pairs, segments, 1) of the largest search
  *   keys_ws_dev       : uint64[2 * n_search] scratch
  *   pair_order_dev    : int32[total pairs] from sushi_hip_fft_pair_order for the SAME ws_bytes, or NULL
  *   keys_ws_dev       : on completion the float32 at byte offset 8 * (n_search + k) is |FFT score - exact score|
- *                       of search k's result position (0 for searches finished by the direct kernel): the
+ *                       of search k's result position (0 for searches finished by a fallback kernel): the
  *                       measured error of the ranking stage, to be compared with delta / 2
  *   flags_dev         : int32[2 * n_search + 2] scratch; on completion flags[k] = 1 if search k had too
- *                       many near-ties and was finished by the direct kernel (and so carries
- *                       sushi_hip_match_batch's accuracy contract), flags[n_search] = how many */
+ *                       many near-ties (or a pattern shorter than 2048 samples) and was finished by a fallback
+ *                       kernel that evaluates every position: float32 streams exactly in float64 from the samples
+ *                       themselves, uint8 streams by the MFMA kernel (exact on integers); flags[n_search] = how many */
 SUSHI_HIP_API int sushi_hip_match_batch_fft(const float* dst_xc_dev, const double* dst_s1_dev, const double* dst_s2_dev, int64_t dst_len,
                               const float* dst_urel_dev, const double* dst_base_dev, const void* dst_spec_dev,
                               const float* src_xc_dev, const double* src_s1_dev, const double* src_s2_dev, int64_t src_len,

@@ -12,7 +12,7 @@ namespace sushi {
 
 constexpr int FFT_HOP = 4096;            // result positions per overlap-save block (= fft_core N / 2)
 constexpr int FFT_CAND = 8;              // candidate slots per block pair (+1 truncation marker)
-// Patterns shorter than this are finished by the direct kernel: the float32 error of an FFT'd cross term is
+// Patterns shorter than this are finished by the fallback kernel (every position evaluated): the float32 error of an FFT'd cross term is
 // relative to |T| * |the whole 2*FFT_HOP-sample block|, not to |T| * |the window|, so for M samples it is
 // ~sqrt(2 * FFT_HOP / M) times larger in score units than the `delta` margin was measured for.
 constexpr int FFT_MIN_TMPL = 2048;

@@ -22,7 +22,7 @@ int launch_refine(const StreamRefs& r, const SushiHipSearch* searches_dev, int f
                   int sub_first_pair, const unsigned long long* cand_dev, unsigned long long* gkeys_dev,
                   float delta, unsigned long long* keys_dev, int* flags_dev, int n_search, hipStream_t st);
 // Direct (MFMA) kernel over the searches the refinement flagged.
-int launch_flagged_direct(const StreamRefs& r, const SushiHipSearch* searches_dev, int n_search,
+int launch_flagged(const StreamRefs& r, const SushiHipSearch* searches_dev, int n_search,
                           unsigned long long* keys_dev, const int* flags_dev, hipStream_t st);
 int launch_unpack(const unsigned long long* keys_dev, int n, int32_t* out_idx_dev, float* out_score_dev, hipStream_t st);
 

@@ -242,11 +242,11 @@ class SearchBatch(object):
 
     def ranking_errors(self):
         """FFT path: |f32 FFT score - exact score| at every search's result position in the last run()
-        (0 for searches the direct kernel finished) -- to be compared with delta / 2."""
+        (0 for searches a fallback kernel finished) -- to be compared with delta / 2."""
         if self.path != "fft":
             return np.zeros(self.n, np.float32)
         return self.keys[self.n:2 * self.n].cpu().numpy().astype(np.uint64).astype(np.uint32).view(np.float32)
 
     def fallback_count(self):
-        """FFT path: how many searches of the last run() were finished by the direct kernel."""
+        """FFT path: how many searches of the last run() were finished by a fallback kernel (every position evaluated)."""
         return int(self.flags[self.n].item()) if self.path == "fft" else 0
