@@ -255,9 +255,9 @@ void match_flagged_kernel(MatchArgs a, const int* __restrict__ flags) {
 
 // The same job for float32 streams, exactly: sum T*I in float64 over the samples as they are (every product of
 // two float32 values is exact in float64), cv2's epilogue from the float64 prefix sums -- what refine_kernel does
-// for a handful of positions, here for every position of the flagged searches.  ~5x the time of the MFMA kernel,
+// for a handful of positions, here for every position of the flagged searches.  ~3x the time of the MFMA kernel,
 // independent of where the data sit (the MFMA kernel's contract is the mid-level one, include/sushi_hip.h).
-// A work item = XT positions of one flagged search; the pattern is staged XM samples at a time.
+// A work item = XT positions of one flagged search; the pattern is staged XM samples at a time.  34 TFLOP/s of f64.
 constexpr int XT = 1024;
 constexpr int XM = 512;
 
@@ -270,8 +270,12 @@ struct ExactArgs {
 
 __global__ __launch_bounds__(256)
 void exact_flagged_kernel(ExactArgs a, const int* __restrict__ flags) {
-    __shared__ float lt[XM];
-    __shared__ float li[XT + XM];
+    // a thread owns XQ = 4 CONSECUTIVE positions: the pattern samples T[m .. m+3] then meet the seven search samples
+    // I[p .. p+6], of which four are the previous step's -- one 16-byte LDS read of each per 16 float64 FMAs
+    constexpr int XQ = XT / 256;
+    static_assert(XQ == 4 && XM % 4 == 0, "the inner loop is written for four positions and four pattern samples a step");
+    __shared__ __attribute__((aligned(16))) float lt[XM];
+    __shared__ __attribute__((aligned(16))) float li[XT + XM];
     __shared__ unsigned long long red[4];
     const int n_flagged = flags[a.n_search];
     if (n_flagged == 0) return;
@@ -292,18 +296,27 @@ void exact_flagged_kernel(ExactArgs a, const int* __restrict__ flags) {
         const float* __restrict__ T = (const float*)a.r.src_raw + sd.tmpl_off;
         const float* __restrict__ I = (const float*)a.r.dst_raw + sd.win_start + p0;
         const int64_t room = a.r.dst_len - (sd.win_start + p0);        // samples of the stream from I on
-        double acc[XT / 256];
-#pragma unroll
-        for (int q = 0; q < XT / 256; ++q) acc[q] = 0.0;
+        double acc[XQ] = {0.0, 0.0, 0.0, 0.0};
         for (int m0 = 0; m0 < M; m0 += XM) {
             const int mc = min(XM, M - m0);
-            for (int e = tid; e < XM; e += 256) lt[e] = e < mc ? T[m0 + e] : 0.f;
+            for (int e = tid; e < XM; e += 256) lt[e] = e < mc ? T[m0 + e] : 0.f;      // zero padded: whole steps of 4
             for (int e = tid; e < XT + XM; e += 256) li[e] = (int64_t)m0 + e < room ? I[m0 + e] : 0.f;
             __syncthreads();
-            for (int m = 0; m < mc; ++m) {
-                const double t = (double)lt[m];
+            const float4* __restrict__ li4 = reinterpret_cast<const float4*>(li) + tid;   // li[4 tid + 4 k ..]
+            const float4* __restrict__ lt4 = reinterpret_cast<const float4*>(lt);
+            float4 lo = li4[0];
+            for (int k = 0; k < (mc + 3) / 4; ++k) {
+                const float4 hi = li4[k + 1];
+                const float4 t4 = lt4[k];
+                const double w[8] = {(double)lo.x, (double)lo.y, (double)lo.z, (double)lo.w,
+                                     (double)hi.x, (double)hi.y, (double)hi.z, (double)hi.w};
+                const double t[4] = {(double)t4.x, (double)t4.y, (double)t4.z, (double)t4.w};
 #pragma unroll
-                for (int q = 0; q < XT / 256; ++q) acc[q] = __builtin_fma(t, (double)li[tid + 256 * q + m], acc[q]);
+                for (int j = 0; j < 4; ++j) {                          // pattern samples in order: one accumulation order per position
+#pragma unroll
+                    for (int q = 0; q < XQ; ++q) acc[q] = __builtin_fma(t[j], w[q + j], acc[q]);
+                }
+                lo = hi;
             }
             __syncthreads();
         }
@@ -311,8 +324,8 @@ void exact_flagged_kernel(ExactArgs a, const int* __restrict__ flags) {
         const double* __restrict__ w2 = a.r.dst_s2 + sd.win_start;
         unsigned long long best = NO_KEY;
 #pragma unroll
-        for (int q = 0; q < XT / 256; ++q) {
-            const int p = p0 + tid + 256 * q;
+        for (int q = 0; q < XQ; ++q) {
+            const int p = p0 + XQ * tid + q;
             if (p < sd.n_pos) {
                 const unsigned long long key = make_key(score_exact(acc[q], ts, w2, (int64_t)p, M), (unsigned)p);
                 best = key < best ? key : best;
