@@ -41,6 +41,8 @@ def main():
         t0 = time.perf_counter()
         calculate_shifts(src, dst, [[x] for x in ev], 10, 30, 5)
         t_seq = time.perf_counter() - t0
+        warm = [ScriptEvent(s, e) for s, e in spans]                    # first batched launch of the process: workspace
+        calculate_shifts_batched(src, dst, [[x] for x in warm], 10, 30, 5)   # allocation, not what is being measured
         ev2 = [ScriptEvent(s, e) for s, e in spans]
         t0 = time.perf_counter()
         proxy = calculate_shifts_batched(src, dst, [[x] for x in ev2], 10, 30, 5)
