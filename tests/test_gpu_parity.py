@@ -320,6 +320,46 @@ def test_known_answers_by_hand(variant):
         assert abs(float(score[0]) - want_score) <= 6e-8 + 1e-7 * want_score
 
 
+def test_c_abi_rejects_bad_arguments_with_real_device_pointers():
+    """Error behaviour of the boundary (include/sushi_hip.h): negative codes, nothing launched, nothing thrown."""
+    import torch
+    from sushi_amd import _native
+    from sushi_amd.device import DeviceStream, SearchBatch
+    L = _native.lib()
+    rng = np.random.default_rng(0)
+    d = DeviceStream(rng.random(50000, dtype=np.float32))
+    b = SearchBatch(d, d, [100], [5000], [0], [30000], path="fft")
+    args = lambda **kw: dict(dict(ws=b.ws.data_ptr(), ws_bytes=b.ws_bytes, delta=b.delta, dtype=d.dtype_code,  # noqa: E731
+                                  xc=d.xc.data_ptr(), n=b.n), **kw)
+
+    def call(ws, ws_bytes, delta, dtype, xc, n, host_desc=None):
+        hd = b.host_desc if host_desc is None else host_desc
+        return L.sushi_hip_match_batch_fft(xc, d.s1.data_ptr(), d.s2.data_ptr(), d.n, d.urel.data_ptr(), d.base.data_ptr(),
+                                           b.spec.data_ptr(), d.xc.data_ptr(), d.s1.data_ptr(), d.s2.data_ptr(), d.n,
+                                           d.raw.data_ptr(), d.raw.data_ptr(), dtype, _native.SQDIFF_NORMED,
+                                           b.desc.data_ptr(), hd.ctypes.data, n, delta, ws, ws_bytes,
+                                           b.keys.data_ptr(), b.flags.data_ptr(), None, b.out_idx.data_ptr(),
+                                           b.out_score.data_ptr(), None)
+    assert call(**args()) == 0
+    assert call(**args(delta=0.0)) == -1 and call(**args(delta=2.0)) == -1            # SUSHI_HIP_EINVAL
+    assert call(**args(dtype=7)) == -1 and call(**args(n=0)) == -1
+    assert call(**args(xc=d.xc.data_ptr() + 4)) == -2                                # SUSHI_HIP_EALIGN
+    assert call(**args(ws=b.ws.data_ptr() + 64)) == -2
+    assert call(**args(ws_bytes=4096)) == -4                                         # SUSHI_HIP_ENOSPACE
+    wrong = b.host_desc.copy()
+    wrong["first_pair"][0] = 3                                                       # layout sums are re-derived and checked
+    assert call(**args(host_desc=wrong)) == -1
+    torch.cuda.synchronize()
+    idx, score = b.results()                                                         # the one valid call's result is intact
+    assert 0 <= int(idx[0]) < 30000 and 0.0 <= float(score[0]) <= 1.0
+    # the host layer turns what it can detect before any launch into SushiError
+    from sushi_amd.common import SushiError
+    with pytest.raises(SushiError):
+        SearchBatch(d, d, [100], [5000], [0], [46000], path="fft")                   # window runs past the stream
+    with pytest.raises(SushiError):
+        SearchBatch(d, DeviceStream(rng.integers(0, 255, 100, dtype=np.uint8)), [0], [10], [0], [10])   # mixed sample types
+
+
 # ----------------------------------------------------------------------------------------------
 # FFT path specifics
 # ----------------------------------------------------------------------------------------------
