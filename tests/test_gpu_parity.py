@@ -577,3 +577,36 @@ def test_random_shapes_property(seed, L, frac, u8, path, scale):
     idx, score = _run_batch(dst, src, [1], [M], [2], [L - M + 1], path)
     res = O.match_template_direct(dst[2:2 + L], src[1:1 + M])[0]
     (_check_u8 if u8 else _check_f32)(res, idx[0], score[0])
+
+
+@pytest.mark.gpu
+def test_alternative_transform_shape_gives_identical_results(tmp_path):
+    """SUSHI_HIP_IFFT_SHAPE=256 (256 threads x 32 points, whole-element exchange) is a different kernel instantiation
+    around the same scoring code: same indices and scores as the default shape, bit for bit (both feed the same
+    exact refinement).  The knob is read once per process, hence the subprocesses."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "run_shape.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from sushi_amd.device import DeviceStream, SearchBatch\n"
+        "rng = np.random.default_rng(12)\n"
+        "dst = rng.random(400000, dtype=np.float32); src = dst[5000:200000].copy()\n"
+        "src += (rng.standard_normal(src.shape[0]) * 0.01).astype(np.float32)\n"
+        "d, s = DeviceStream(dst), DeviceStream(src)\n"
+        "offs = [1000, 40000, 90000, 150000]; lens = [30000, 4097, 12000, 40000]\n"
+        "b = SearchBatch(d, s, offs, lens, [0, 20000, 50000, 100000], [300001, 100000, 200000, 250000], path='fft')\n"
+        "b.run(); i, sc = b.results()\n"
+        "print(' '.join(str(int(x)) for x in i), ' '.join(repr(float(x)) for x in sc), b.fallback_count())\n"
+        % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for shape in ("512", "256"):
+        env = dict(os.environ, SUSHI_HIP_IFFT_SHAPE=shape)
+        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
+    idx = [int(x) for x in outs[0].split()[:4]]
+    assert idx == [6000, 25000, 45000, 55000]                       # planted: pattern k sits at 5000 + offs[k] - win_start[k]
