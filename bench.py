@@ -92,8 +92,8 @@ def cpu_baseline(dst_row, src_row, offs, lens, wst, npos, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)   # the shader clock takes ~3 steps to ramp (tools/gpu_clock.sh)
     ap.add_argument("--events", type=int, default=1000, help="events per GPU (BASELINE configs[1]: 1000)")
     ap.add_argument("--minutes", type=float, default=45.0)
     ap.add_argument("--window", type=float, default=60.0)
