@@ -188,6 +188,14 @@ def main():
             idx, score = gather_results(idx, score, n_total)
         return idx, score
 
+    # one untimed verification pass before anything is timed: a batch that does not recover the planted offset is
+    # not worth measuring (it also pages the kernels in; the W warm-up steps below are the contract's)
+    v_idx, _ = step()
+    sync()
+    v_times = np.array(start_times) + v_idx.cpu().numpy().astype(np.float64) / float(args.rate)
+    v_err = np.abs((v_times - np.array([s for s, _ in events])) - args.offset) * args.rate
+    if float(v_err.max()) > 1.0:
+        raise SystemExit("verification pass: planted offset not recovered (max error %.3f samples)" % float(v_err.max()))
     for _ in range(args.warmup):
         step()
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
