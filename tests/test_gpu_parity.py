@@ -546,7 +546,7 @@ def test_no_match_anywhere_ties_at_one(oracle, variant):
 from hypothesis import given, settings, strategies as st
 
 
-@settings(max_examples=100, deadline=None)
+@settings(max_examples=100, deadline=None, derandomize=True)   # the same examples on every run; tools/prop_hunt.py is the random hunt
 @given(seed=st.integers(0, 2 ** 31 - 1), L=st.integers(1, 30000), frac=st.floats(0.0, 1.0), u8=st.booleans(),
        path=st.sampled_from([0, 2, "fft"]), scale=st.sampled_from([1.0, 1e-3, 1e-6, 40.0]))
 def test_random_shapes_property(seed, L, frac, u8, path, scale):
