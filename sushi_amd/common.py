@@ -1,4 +1,5 @@
 """Names the hot path shares with the reference's ``common.py``."""
+import math
 
 
 class SushiError(Exception):
@@ -11,8 +12,13 @@ def clip(value, minimum, maximum):
     return max(min(value, maximum), minimum)
 
 
+def py2_round(x):
+    """Python 2's round(): half away from zero (the reference is Python 2: common.py:32, wav.py:127)."""
+    return math.floor(x + 0.5) if x >= 0 else -math.floor(-x + 0.5)
+
+
 def format_time(seconds):
     """common.py:31-38 (h:mm:ss.cc, as in the reference's log lines)"""
-    cs = round(seconds * 100)
+    cs = py2_round(seconds * 100)
     return u'{0}:{1:02d}:{2:02d}.{3:02d}'.format(int(cs // 360000), int((cs // 6000) % 60),
                                                  int((cs // 100) % 60), int(cs % 100))

@@ -13,12 +13,7 @@ import numpy as np
 import torch
 
 from . import _native
-from .common import SushiError
-
-
-def _py2_round(x):
-    """Python 2 round(): half away from zero (wav.py:127)."""
-    return math.floor(x + 0.5) if x >= 0 else -math.floor(-x + 0.5)
+from .common import SushiError, py2_round
 
 
 def _select(L, data, n, side, rank, hist, stream):
@@ -73,8 +68,8 @@ def build_on_device(samples, framerate, frames_count, sample_rate, sample_type, 
     chunk = int(read_chunk_size * framerate)
     n_raw = int(samples.shape[0])
     n_full, rest = divmod(n_raw, chunk)
-    nl_full = int(_py2_round(chunk * downsample_rate))
-    nl_rest = int(_py2_round(rest * downsample_rate)) if rest else 0
+    nl_full = int(py2_round(chunk * downsample_rate))
+    nl_rest = int(py2_round(rest * downsample_rate)) if rest else 0
     if downsample_rate != 1 and (nl_full <= 0):
         raise SushiError('sample rate too low for one-second chunks')
     scale_full = 1.0 / (float(nl_full) / float(chunk)) if nl_full > 0 else 0.0

@@ -18,15 +18,10 @@ from time import time
 
 import numpy as np
 
-from .common import SushiError, clip
+from .common import SushiError, clip, py2_round
 
 WAVE_FORMAT_PCM = 0x0001
 WAVE_FORMAT_EXTENSIBLE = 0xFFFE
-
-
-def _py2_round(x):
-    """Python 2 round(): half away from zero (the reference is Python 2; wav.py:127)."""
-    return math.floor(x + 0.5) if x >= 0 else -math.floor(-x + 0.5)
 
 
 class DownmixedWavFile(object):
@@ -223,7 +218,7 @@ class WavStream(object):
             for length, count, start in ((chunk, n_full, 0), (rest, 1 if rest else 0, n_full * chunk)):
                 if count == 0 or length == 0:
                     continue
-                new_length = int(_py2_round(length * downsample_rate))
+                new_length = int(py2_round(length * downsample_rate))
                 if new_length <= 0:
                     continue
                 scale_x = 1.0 / (float(new_length) / float(length))

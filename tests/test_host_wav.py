@@ -155,3 +155,15 @@ def test_window_arithmetic_matches_oracle_for_any_request(centre, window, m, rat
     o_start, o_lo, o_hi = o.search_bounds(m, centre, window)
     assert start_time == o_start and lo == o_lo
     assert n_pos == max(o_hi - o_lo, 0) - m + 1
+
+
+def test_format_time_reference_vectors():
+    """The reference's own known answers (tests/main.py:220-235 FormatTimeTestCase) plus Python 2's rounding of
+    halves (common.py:32 `round` under Python 2 rounds half away from zero: 0.005 s -> .01)."""
+    from sushi_amd.common import format_time
+    assert format_time(0) == '0:00:00.00'
+    assert format_time(65) == '0:01:05.00'
+    assert format_time(5.559) == '0:00:05.56'
+    assert format_time(3600 + 60 * 15 + 35.15) == '1:15:35.15'
+    assert format_time(544.997) == '0:09:05.00'
+    assert format_time(0.005) == '0:00:00.01' and format_time(0.025) == '0:00:00.03'
