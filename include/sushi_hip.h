@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SUSHI_HIP_ABI_VERSION 4
+#define SUSHI_HIP_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define SUSHI_HIP_API __attribute__((visibility("default")))
@@ -139,6 +139,10 @@ SUSHI_HIP_API int sushi_hip_fft_layout(int64_t win_start, int32_t n_pos, int32_t
  * total as ONE sub-batch (the call splits a batch into sub-batches that fit the workspace it is given;
  * more workspace = fewer, larger launches; the minimum is what the largest single search needs). */
 SUSHI_HIP_API size_t sushi_hip_fft_workspace_bytes(int64_t n_pairs, int64_t n_seg, int64_t n_search);
+
+/* How many sub-batches sushi_hip_match_batch_fft cuts these searches into for a workspace of ws_bytes
+ * (>= 1), or a negative SUSHI_HIP_E* code (ENOSPACE: some search does not fit on its own). */
+SUSHI_HIP_API int sushi_hip_fft_sub_batches(const SushiHipSearch* searches_host, int n_search, size_t ws_bytes);
 
 /* Optional L2-friendly schedule of the inverse-transform workgroups: order_host[total pairs of the batch]
  * receives, per sub-batch (as cut for a workspace of ws_bytes), a permutation of the sub-batch's pairs in

@@ -18,9 +18,11 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sushi_hip.h")
 U8, F32 = 0, 1
 SQDIFF_NORMED = 0
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NSTAGES = 5
 STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish")
+STAGE_KERNELS = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "ifft_kernel", "refine": "refine_kernel",
+                 "finish": "exact_flagged_kernel|match_flagged_kernel+unpack_keys_kernel"}
 
 # struct SushiHipSearch, 40 bytes
 SEARCH_DTYPE = np.dtype([("tmpl_off", "<i8"), ("win_start", "<i8"), ("tmpl_len", "<i4"),
@@ -85,6 +87,8 @@ def lib():
     L.sushi_hip_match_batch_fft.restype = ci
     L.sushi_hip_match_batch_fft.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, ci, ci, vp, vp, ci, dbl,
                                             vp, sz, vp, vp, vp, vp, vp, vp]
+    L.sushi_hip_fft_sub_batches.restype = ci
+    L.sushi_hip_fft_sub_batches.argtypes = [vp, ci, sz]
     L.sushi_hip_fft_pair_order.restype = ci
     L.sushi_hip_fft_pair_order.argtypes = [vp, ci, sz, vp, i64]
     u32, cf = ctypes.c_uint32, ctypes.c_float

@@ -157,6 +157,7 @@ class SearchBatch(object):
         if (n_pos > 0x7fffffff - 65536).any() or (tmpl_len > 0x7fffffff - 65536).any():
             raise SushiError("search too large")
         self.n = n
+        self.sub_batches = 1
         self.path = default_path() if path is None else path
         if self.path not in ("fft", "direct"):
             raise SushiError("path must be 'fft' or 'direct'")
@@ -181,14 +182,19 @@ class SearchBatch(object):
             desc["first_pair"][1:] = np.cumsum(pairs[:-1])
             desc["first_seg"][1:] = np.cumsum(segs[:-1])
             L = _native.lib()
-            k_big = int(np.argmax(pairs * 65536 + segs * 65536))
-            need_one = int(L.sushi_hip_fft_workspace_bytes(int(pairs[k_big]), int(segs[k_big]), 1))
+            # what the most demanding single search needs (pairs and segments weigh differently, and the
+            # alignment padding is per array: ask the library for every distinct (pairs, segments) shape)
+            shapes = np.unique(np.stack([pairs, segs], axis=1), axis=0)
+            need_one = max(int(L.sushi_hip_fft_workspace_bytes(int(p_), int(s_), 1)) for p_, s_ in shapes)
             need_all = int(L.sushi_hip_fft_workspace_bytes(int(pairs.sum()), int(segs.sum()), n))
             if workspace_bytes is None:
                 workspace_bytes = int(os.environ.get("SUSHI_HIP_FFT_WS_MB", DEFAULT_FFT_WORKSPACE >> 20)) << 20
             self.ws_bytes = max(need_one, min(need_all, int(workspace_bytes)))
             self.delta = float(delta)
             self.fft_pairs, self.fft_segs = int(pairs.sum()), int(segs.sum())
+            self.sub_batches = int(L.sushi_hip_fft_sub_batches(desc.ctypes.data, n, self.ws_bytes))
+            if self.sub_batches < 1:
+                _native.check(self.sub_batches, "sushi_hip_fft_sub_batches")
             # L2-friendly schedule of the inverse-transform workgroups (host side, once per batch)
             self.host_order = np.empty(self.fft_pairs, np.int32)
             _native.check(L.sushi_hip_fft_pair_order(desc.ctypes.data, n, self.ws_bytes, self.host_order.ctypes.data,

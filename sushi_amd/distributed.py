@@ -51,22 +51,34 @@ class ShardedSearch(object):
     """Runs this rank's block of a global descriptor list and gathers everyone's results.
 
     `make_batch(lo, hi)` must return an object with `.run()` -> (idx, score) device tensors for
-    searches [lo, hi) (a `SearchBatch` on the GPU; the CPU tests pass a stand-in)."""
+    searches [lo, hi) (a `SearchBatch` on the GPU; the CPU tests pass a stand-in).  `device`: where a rank
+    WITHOUT searches (more ranks than searches) allocates its empty contribution -- RCCL gathers device
+    tensors only, so it must be this rank's GPU under the nccl backend (None: CPU, for gloo)."""
 
-    def __init__(self, n_total, make_batch, group=None):
+    def __init__(self, n_total, make_batch, group=None, device=None):
         self.n_total = n_total
         self.group = group
+        self.device = device
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.lo, self.hi = shard_bounds(n_total, self.rank, self.world)
         self.batch = make_batch(self.lo, self.hi) if self.hi > self.lo else None
 
-    def run(self):
+    def all_bounds(self):
+        return [shard_bounds(self.n_total, r, self.world) for r in range(self.world)]
+
+    def run_local(self):
+        """This rank's block: (idx int32[hi - lo], score float32[hi - lo]) on this rank's device."""
         if self.batch is not None:
-            idx, score = self.batch.run()
-        else:
-            idx = torch.empty(0, dtype=torch.int32)
-            score = torch.empty(0, dtype=torch.float32)
+            return self.batch.run()
+        dev = self.device if self.device is not None else torch.device("cpu")
+        return torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.float32, device=dev)
+
+    def gather(self, idx, score):
+        """The one collective of the path: everyone's (idx, score) in global search order."""
         if self.world == 1:
             return idx, score
         return gather_results(idx, score, self.n_total, self.group)
+
+    def run(self):
+        return self.gather(*self.run_local())

@@ -22,6 +22,56 @@ def make_dst_pcm(seconds, rate=12000, seed=0):
     return np.round(y).astype(np.int16)
 
 
+def make_hard_dst_pcm(seconds, rate=12000, seed=0, period_s=60.0):
+    """make_dst_pcm plus, every `period_s` seconds, what real soundtracks hold and filtered noise does not:
+    2.5 s of digital silence, 2.5 s of a held 400 Hz tone (an exact 30-sample period at 12 kHz: every window a
+    period apart scores the same) and a 1.5 s jingle that is the same samples at every occurrence.
+    Returns (int16 pcm, [(kind, start_s, end_s), ...])."""
+    pcm = make_dst_pcm(seconds, rate, seed=seed).copy()
+    rng = np.random.default_rng(seed + 1000)
+    jingle = make_dst_pcm(1.5, rate, seed=seed + 1001)
+    spans = []
+    t = 20.0
+    n = pcm.shape[0]
+    while t + 12.0 < seconds - 20.0:
+        a = int(round(t * rate))
+        pcm[a:a + int(2.5 * rate)] = 0
+        spans.append(("silence", t, t + 2.5))
+        b = int(round((t + 5.0) * rate))
+        k = np.arange(int(2.5 * rate))
+        pcm[b:b + k.shape[0]] = np.round(6000.0 * np.sin(2 * math.pi * k * (400.0 / rate))).astype(np.int16)
+        spans.append(("tone", t + 5.0, t + 7.5))
+        c = int(round((t + 10.0) * rate))
+        pcm[c:c + jingle.shape[0]] = jingle
+        spans.append(("jingle", t + 10.0, t + 11.5))
+        t += period_s + float(rng.uniform(0.0, 1.0))
+    assert pcm.shape[0] == n
+    return pcm, spans
+
+
+def plant_hard_events(events, spans, offset_s, frac, seed=4):
+    """Replace a fraction `frac` of `events` (source-time spans) by events cut from the hard spans of the
+    destination (`spans` are destination times; source time = destination time - offset).  Returns the re-sorted
+    event list and a bool mask of the planted ones."""
+    rng = np.random.default_rng(seed)
+    n = len(events)
+    n_hard = max(1, int(round(frac * n))) if frac > 0 else 0
+    chosen = set(np.linspace(0, n - 1, n_hard).astype(int).tolist()) if n_hard else set()
+    starts = np.array([s for _, s, _ in spans])
+    out = []
+    for k, (s, e) in enumerate(events):
+        if k in chosen:
+            j = int(np.argmin(np.abs(starts - (s + offset_s))))
+            kind, a, b = spans[j]
+            ns = a - offset_s + float(rng.uniform(0.05, 0.25))
+            ne = min(ns + float(rng.uniform(1.0, b - a - 0.4)), b - offset_s - 0.05)
+            out.append((ns, ne, True))
+        else:
+            out.append((s, e, False))
+    out.sort(key=lambda x: x[0])
+    return [(s, e) for s, e, _ in out], np.array([h for _, _, h in out], bool)
+
+
 def make_src_pcm(dst_pcm, offsets_samples, snr_db=20.0, seed=1):
     """src[t] = dst[t + off(t)] + white noise at `snr_db`.  `offsets_samples` is an int (global
     offset) or a list of (start_sample, offset) pieces (per-chapter offsets); dst times are

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--events", "24", "--minutes", "3", "--window", "10"]
+           "--config", "1", "--events", "24", "--minutes", "3", "--window", "10", "--cpu-sample", "8"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -22,7 +22,7 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
-    assert d["unit"] == "events/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "events/s" and d["higher_is_better"] is True and d["scaling"] == "strong"
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and abs(d["value"] - 24 * 1000.0 / d["ms_per_step"]) <= 0.02 * d["value"]
@@ -36,4 +36,18 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
     # parity of the whole job against the planted offset and the oracle sample is part of the line
     assert d["parity"]["max_shift_err_samples_vs_planted"] <= 1.0
-    assert d["parity"]["max_idx_err_vs_oracle_sample"] in (0, 1)
+    assert d["parity"]["max_idx_err_vs_oracle_sample"] == 0 and d["parity"]["oracle_sample_searches"] >= 8
+    assert d["config"]["global_events"] == 24 and d["config"]["events_per_gpu"] == [24]
+    assert "custom" in d["config"]["workload"]
+
+
+def test_bench_default_workload_is_the_north_star_configuration():
+    """No flags = BASELINE configs[2]: 3000 events, 2-h 12 kHz streams, +-120 s window (the target's configuration)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    c = bench.CONFIGS[2]
+    assert (c["events"], c["minutes"], c["window"], c["rate"]) == (3000, 120.0, 120.0, 12000)
+    import inspect
+    assert 'default=2' in inspect.getsource(bench.main)

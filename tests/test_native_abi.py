@@ -24,7 +24,7 @@ def test_library_builds_and_exports_all_declared_symbols():
 
 def test_host_only_entry_points():
     L = _native.lib()
-    assert L.sushi_hip_abi_version() == 4
+    assert L.sushi_hip_abi_version() == 5
     assert L.sushi_hip_strerror(0) == b"ok" and b"invalid" in L.sushi_hip_strerror(-1)
     assert _native.variant_tiles() == [1024, 4096, 16384]
     assert L.sushi_hip_variant_tile_positions(99) == -1
