@@ -163,15 +163,32 @@ def main():
     rate = cfg["rate"]
     seconds = cfg["minutes"] * 60.0
     seed = 20260924 + args.config
+    # SUSHI_BENCH_CACHE=<dir>: keep the normalised streams of a workload between runs on one box (the profiling
+    # scripts run this file several times; generating 2 x 86 M samples takes longer than the measurement)
+    cache = os.environ.get("SUSHI_BENCH_CACHE")
+    tag = "c%d_%g_%d_%s_%g_%g" % (args.config, cfg["minutes"], rate, args.sample_type, args.offset, args.hard_frac)
+    cpath = os.path.join(cache, tag + ".npz") if cache else None
     hard_spans = []
-    if args.hard_frac > 0:
-        dst_pcm, hard_spans = synth.make_hard_dst_pcm(seconds, rate, seed=seed)
+    if cpath and os.path.exists(cpath):
+        z = np.load(cpath, allow_pickle=True)
+        dst = WavStream.from_prepared(z["dst"], rate, int(z["sample_count"]), int(z["padding_size"]))
+        src = WavStream.from_prepared(z["src"], rate, int(z["sample_count"]), int(z["padding_size"]))
+        hard_spans = [tuple(x) for x in z["hard_spans"].tolist()]
+        hard_spans = [(k, float(a), float(b)) for k, a, b in hard_spans]
     else:
-        dst_pcm = synth.make_dst_pcm(seconds, rate, seed=seed)
-    src_pcm = synth.make_src_pcm(dst_pcm, int(round(args.offset * rate)), seed=seed + 1)
-    dst = WavStream.from_samples(dst_pcm, rate, sample_rate=rate, sample_type=args.sample_type)
-    src = WavStream.from_samples(src_pcm, rate, sample_rate=rate, sample_type=args.sample_type)
-    del dst_pcm, src_pcm
+        if args.hard_frac > 0:
+            dst_pcm, hard_spans = synth.make_hard_dst_pcm(seconds, rate, seed=seed)
+        else:
+            dst_pcm = synth.make_dst_pcm(seconds, rate, seed=seed)
+        src_pcm = synth.make_src_pcm(dst_pcm, int(round(args.offset * rate)), seed=seed + 1)
+        dst = WavStream.from_samples(dst_pcm, rate, sample_rate=rate, sample_type=args.sample_type)
+        src = WavStream.from_samples(src_pcm, rate, sample_rate=rate, sample_type=args.sample_type)
+        del dst_pcm, src_pcm
+        if cpath and rank == 0:
+            os.makedirs(cache, exist_ok=True)
+            np.savez(cpath + ".tmp.npz", dst=dst.data, src=src.data, sample_count=dst.sample_count,
+                     padding_size=dst.padding_size, hard_spans=np.array(hard_spans, dtype=object))
+            os.replace(cpath + ".tmp.npz", cpath)
     n_total = cfg["events"]
     events = synth.make_events(n_total, seconds, cfg["window"] + abs(args.offset), seed=seed + 2)
     hard_mask = np.zeros(n_total, bool)

@@ -68,6 +68,14 @@ def plant_hard_events(events, spans, offset_s, frac, seed=4):
             out.append((ns, ne, True))
         else:
             out.append((s, e, False))
+    # an ordinary event whose destination span touches a hard span is a hard search too (its pattern holds part of
+    # a tone / a jingle that recurs elsewhere in the window)
+    ends = np.array([b for _, _, b in spans])
+    for k, (s, e, h) in enumerate(out):
+        if not h:
+            j = int(np.searchsorted(starts, e + offset_s)) - 1
+            if j >= 0 and s + offset_s < ends[j]:
+                out[k] = (s, e, True)
     out.sort(key=lambda x: x[0])
     return [(s, e) for s, e, _ in out], np.array([h for _, _, h in out], bool)
 

@@ -178,6 +178,20 @@ class WavStream(object):
         _live_streams.add(self)
         return self
 
+    @classmethod
+    def from_prepared(cls, data, sample_rate, sample_count, padding_size, device=None):
+        """Wrap a (1, N) row that already is what wav.py:113-156 produces (e.g. a saved ``WavStream.data``)."""
+        data = np.ascontiguousarray(data)
+        if data.ndim != 2 or data.shape[0] != 1 or data.dtype not in (np.dtype(np.uint8), np.dtype(np.float32)):
+            raise SushiError('Unknown sample type of WAV stream, must be uint8 or float32')
+        self = cls.__new__(cls)
+        self.data, self.sample_rate, self.sample_count, self.padding_size = data, sample_rate, sample_count, padding_size
+        self._dev_row = None
+        self._device = device
+        self._dev = None
+        _live_streams.add(self)
+        return self
+
     def _build(self, samples, framerate, frames_count, sample_rate, sample_type):
         """wav.py:113-156: on the GPU if there is one (the normalised row then stays in HBM for the
         matching), else in NumPy."""
