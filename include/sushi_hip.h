@@ -6,26 +6,21 @@
  * `ndarray.argmin` (wav.py:186) in-process.  These entry points are what a ctypes binding
  * inside a drop-in `wav.py` binds instead of `import cv2`:
  *
- *   sushi_hip_prepare_stream   replaces the per-call work cv2 redoes on `self.data`
- *                              (CV_64F integral of the search image, templmatch.cpp
- *                              common_matchTemplate) by doing it once per WavStream
- *                              (wav.py:108-162 builds `self.data`; this runs right after).
- *   sushi_hip_match_batch      replaces wav.py:185-186 for a whole batch of
- *                              (pattern, window) pairs; one launch, one (index, score) per pair.
- *                              Direct form: exact-f32 MFMA sliding dot product, O(P*M).
- *   sushi_hip_prepare_spectra  block DFTs of the search stream, once per WavStream (cv2's crossCorr
- *                              recomputes them inside every matchTemplate call).
- *   sushi_hip_match_batch_fft  the same contract as sushi_hip_match_batch through overlap-save FFT
- *                              (what cv2's crossCorr does): f32 FFT scores for every position, then
- *                              the exact float64 evaluation of every position within `delta` of the
- *                              minimum; searches with too many near-ties are finished by a kernel that evaluates
- *                              every position (float64 for float32 streams, the MFMA kernel for uint8).
+ *   sushi_hip_stream_create    once per WavStream, right after wav.py:108-162 has built `self.data`:
+ *                              what cv2 redoes inside every matchTemplate call on the search image
+ *                              (the CV_64F integral of common_matchTemplate, the block DFTs of crossCorr)
+ *                              is done once per stream and kept in HBM.
+ *   sushi_hip_batch_create     a batch of find_substream calls after their window arithmetic
+ *                              (wav.py:178-184): one SushiHipRequest per call.
+ *   sushi_hip_batch_run        replaces wav.py:185-186 for the whole batch: one (index, score) per request.
  *
- * Conventions: extern "C", plain pointers and sizes, no C++ or torch types.  Every pointer
- * named *_dev is a device (HBM) pointer owned by the caller for the duration of the call's
- * execution on `hip_stream`; nothing is retained.  `hip_stream` is a hipStream_t passed as
- * void* (NULL = the default stream).  Calls are asynchronous with respect to the host and
- * return 0 or a negative SUSHI_HIP_E* code; no exception crosses the boundary.
+ * Conventions: extern "C", plain pointers and sizes, no C++ or torch types.  Every pointer named *_dev is a
+ * device (HBM) pointer owned by the caller; *_host pointers are host memory read during the call only.
+ * The library allocates NO device memory: a handle is built inside a buffer the caller provides
+ * (sushi_hip_*_bytes tells its size) and the caller keeps that buffer -- and, for a stream, the samples --
+ * alive until the handle is destroyed.  `hip_stream` is a hipStream_t passed as void* (NULL = the default
+ * stream).  Calls are asynchronous with respect to the host and return 0 or a negative SUSHI_HIP_E* code;
+ * no exception crosses the boundary.  A handle may be used from one host thread at a time.
  */
 #ifndef SUSHI_HIP_H
 #define SUSHI_HIP_H
@@ -47,33 +42,19 @@ extern "C" {
 
 /* error codes */
 #define SUSHI_HIP_OK 0
-#define SUSHI_HIP_EINVAL (-1)    /* bad argument (null pointer, negative size, unknown dtype/method/variant) */
+#define SUSHI_HIP_EINVAL (-1)    /* bad argument (null pointer, negative size, unknown dtype/path/variant, request outside its stream) */
 #define SUSHI_HIP_EALIGN (-2)    /* a device pointer is not aligned as documented */
-#define SUSHI_HIP_ELAUNCH (-3)   /* the HIP runtime rejected a launch / memset (see hipGetLastError) */
-#define SUSHI_HIP_ENOSPACE (-4)  /* workspace too small */
+#define SUSHI_HIP_ELAUNCH (-3)   /* the HIP runtime rejected a launch / copy / memset (see hipGetLastError) */
+#define SUSHI_HIP_ENOSPACE (-4)  /* buffer or workspace too small */
 #define SUSHI_HIP_ENODEV (-5)    /* no gfx950 device visible */
 
 /* sample types of WavStream.data (wav.py:109: 'uint8' or 'float32') */
 #define SUSHI_HIP_U8 0
 #define SUSHI_HIP_F32 1
 
-/* matching methods.  0 is what the reference uses (wav.py:185). */
-#define SUSHI_HIP_SQDIFF_NORMED 0
-
-/* One search = one call of WavStream.find_substream (wav.py:177-188) after its window
- * arithmetic: `pattern` is src.data[0, tmpl_off : tmpl_off + tmpl_len] and `search_source`
- * is dst.data[0, win_start : win_start + n_pos + tmpl_len - 1]; n_pos = result.shape[1].
- * first_tile = sum over previous searches of ceil(n_pos / tile_positions(variant)). */
-typedef struct SushiHipSearch {
-    int64_t tmpl_off;
-    int64_t win_start;
-    int32_t tmpl_len;
-    int32_t n_pos;
-    int32_t first_tile;   /* direct path: tiles of the searches before this one */
-    int32_t first_pair;   /* FFT path: block pairs of the searches before this one (sushi_hip_fft_layout) */
-    int32_t first_seg;    /* FFT path: template segments of the searches before this one */
-    int32_t reserved;
-} SushiHipSearch;         /* 40 bytes */
+/* how a batch is matched.  Both give the same results (tests/test_gpu_parity.py). */
+#define SUSHI_HIP_PATH_FFT 0     /* overlap-save FFT ranking + exact float64 evaluation of the near-minimum positions */
+#define SUSHI_HIP_PATH_DIRECT 1  /* exact-f32 MFMA sliding dot product, O(P*M) */
 
 SUSHI_HIP_API int sushi_hip_abi_version(void);
 SUSHI_HIP_API const char* sushi_hip_strerror(int code);
@@ -81,116 +62,116 @@ SUSHI_HIP_API const char* sushi_hip_strerror(int code);
 /* 0 if a gfx950 device is current, SUSHI_HIP_ENODEV otherwise. */
 SUSHI_HIP_API int sushi_hip_device_ok(void);
 
-/* Kernel variants differ only in how many result positions one workgroup owns. */
-SUSHI_HIP_API int sushi_hip_variant_count(void);
-SUSHI_HIP_API int sushi_hip_variant_tile_positions(int variant);
+/* ---- streams --------------------------------------------------------------------------------------------
+ * raw_dev: the n samples of the row WavStream.data[0] (`dtype`), already in HBM; they stay the caller's and
+ * are read again by every batch (pattern spectra, exact evaluation).  Built into mem_dev (256-byte aligned,
+ * >= sushi_hip_stream_bytes(n, dtype, searchable) bytes):
+ *   xc[n]      float32  sample - centre (0.5 for float32 data in [0,1], 128 for uint8): the direct path's operand
+ *   s1[n+1], s2[n+1]  float64 exclusive prefix sums of the samples and of their squares AS THEY ARE (the CV_64F
+ *              integral cv2 builds per call; exact for uint8)
+ *   urel[n+1]  float32 + base[nb+1] float64, nb = ceil(n / B), B = sushi_hip_fft_block():
+ *              s2[e] = base[e / B] + urel[e]   (the window energies in the cheap form the FFT scoring reads)
+ *   spectra    (searchable streams only; sushi_hip_stream_add_spectra attaches them later)  for every block
+ *              j = 0 .. nb-1 the N-point complex DFT, N = sushi_hip_fft_size(), H = N - B, of
+ *                  x[jB .. jB+N) + i * x[jB+H .. jB+H+N)         (zeros past the end)
+ *              followed by one all-zero block: sushi_hip_stream_spectra_bytes(n) = (nb + 1) * N * 8 bytes.
+ * A stream that is only a source of patterns does not need spectra. */
+typedef struct SushiHipStream SushiHipStream;
 
-/* Stream preparation.  raw_dev: n samples of `dtype` (the row WavStream.data[0]).
- * Outputs: xc_dev[n] float32 = sample - centre (centre = 0.5 for float32 data in [0,1],
- * 128 for uint8: what the direct MFMA kernel multiplies); s1_dev[n+1] / s2_dev[n+1] float64 exclusive
- * prefix sums of the samples and their squares AS THEY ARE (the CV_64F integral cv2 builds per call; exact
- * for uint8); and the window energies in the cheap form the FFT path's scoring reads: urel_dev[n+1]
- * float32 and base_dev[0 .. nb] float64, nb = ceil(n / B), B = sushi_hip_fft_hop():
- *     s2[e] = sum_{e' < e} sample[e']^2 = base[e / B] + urel[e]          (e = 0 .. n)
- * (base_dev holds 2 * (nb + 1) doubles; the second half is scratch of this call.)
- * raw_dev stays the caller's: the FFT path reads it again (spectra, template spectra, exact refinement).
- * xc_dev must be 16-byte aligned; base_bytes >= sushi_hip_prepare_base_bytes(n). */
-SUSHI_HIP_API size_t sushi_hip_prepare_base_bytes(int64_t n);
+SUSHI_HIP_API int sushi_hip_fft_size(void);      /* N: complex points per transform */
+SUSHI_HIP_API int sushi_hip_fft_block(void);     /* B: samples per block = per pattern segment */
 SUSHI_HIP_API double sushi_hip_centre(int dtype);
-SUSHI_HIP_API int sushi_hip_prepare_stream(const void* raw_dev, int dtype, int64_t n,
-                             float* xc_dev, double* s1_dev, double* s2_dev,
-                             float* urel_dev, double* base_dev, size_t base_bytes, void* hip_stream);
+SUSHI_HIP_API size_t sushi_hip_stream_bytes(int64_t n, int dtype, int searchable);
+SUSHI_HIP_API size_t sushi_hip_stream_spectra_bytes(int64_t n);
+SUSHI_HIP_API int sushi_hip_stream_create(const void* raw_dev, int dtype, int64_t n, int searchable,
+                                          void* mem_dev, size_t mem_bytes, void* hip_stream, SushiHipStream** out);
+SUSHI_HIP_API int sushi_hip_stream_add_spectra(SushiHipStream* stream, void* mem_dev, size_t mem_bytes, void* hip_stream);
+/* Where a part lives (for tests and diagnostics): which = SUSHI_HIP_VIEW_*; SPECTRA gives NULL / 0 before they exist. */
+#define SUSHI_HIP_VIEW_XC 0
+#define SUSHI_HIP_VIEW_S1 1
+#define SUSHI_HIP_VIEW_S2 2
+#define SUSHI_HIP_VIEW_UREL 3
+#define SUSHI_HIP_VIEW_BASE 4
+#define SUSHI_HIP_VIEW_SPECTRA 5
+SUSHI_HIP_API int sushi_hip_stream_view(const SushiHipStream* stream, int which, const void** ptr_dev, size_t* bytes);
+SUSHI_HIP_API void sushi_hip_stream_destroy(SushiHipStream* stream);
 
-/* Batched template match + arg-minimum.
- *   dst_* : prepared search stream (the WavStream find_substream is called on), dst_len samples
- *   src_* : prepared stream the patterns are slices of, src_len samples
- *   centre: the value subtracted by sushi_hip_prepare_stream for these streams' dtype
- *           (the cross terms are accumulated in float32 over xc = sample - centre: exact for uint8; for
- *           float32 the rounding is relative to sum |T - 0.5| |I - 0.5|, which is what makes the kernel at
- *           least as accurate as cv2 on WavStream data -- silence sits at the mid level -- but not on
- *           windows of samples near 0, where sum T I is small itself and float32(sample - 0.5) drops low
- *           bits; sushi_hip_match_batch_fft reads the samples themselves and has no such limit)
- *   searches_dev[n_search], ordered by first_tile; n_tiles = total tile count
- *   keys_ws_dev[n_search] : uint64 scratch
- *   out_idx_dev[n_search]   = result.argmin(axis=1)[0]        (wav.py:186)
- *   out_score_dev[n_search] = result[0][min_idx], float32     (wav.py:188)
- * Preconditions checked by the caller: 1 <= tmpl_len, 1 <= n_pos, tmpl_off + tmpl_len <= src_len,
- * win_start + n_pos + tmpl_len - 1 <= dst_len. */
-SUSHI_HIP_API int sushi_hip_match_batch(const float* dst_xc_dev, const double* dst_s1_dev, const double* dst_s2_dev, int64_t dst_len,
-                          const float* src_xc_dev, const double* src_s1_dev, const double* src_s2_dev, int64_t src_len,
-                          double centre, int method,
-                          const SushiHipSearch* searches_dev, int n_search, int n_tiles, int variant,
-                          uint64_t* keys_ws_dev, int32_t* out_idx_dev, float* out_score_dev,
-                          void* hip_stream);
+/* ---- batches --------------------------------------------------------------------------------------------
+ * One request = one call of WavStream.find_substream (wav.py:177-188) after its window arithmetic: `pattern` is
+ * src.data[0, tmpl_off : tmpl_off + tmpl_len] and `search_source` is
+ * dst.data[0, win_start : win_start + n_pos + tmpl_len - 1]; n_pos = result.shape[1]. */
+typedef struct SushiHipRequest {
+    int64_t tmpl_off;
+    int64_t win_start;
+    int32_t tmpl_len;
+    int32_t n_pos;
+} SushiHipRequest;        /* 24 bytes */
 
-/* ---- overlap-save FFT path ------------------------------------------------------------------
- * The destination stream is cut into blocks of sushi_hip_fft_hop() = B samples; block j is
- * stored as the 2B-point complex DFT of x[jB .. jB+2B) + i * x[(j+1)B .. (j+3)B) (x = the samples as they are; zeros past
- * the end), 2B complex float32 each, followed by one all-zero block:
- * sushi_hip_spectra_bytes(n) = (ceil(n/B) + 1) * 2B * 8 bytes.
- * A search covers the blocks floor(win_start/B) .. floor((win_start+n_pos-1)/B), two per
- * "pair", and its template is cut into ceil(tmpl_len/B) segments. */
-SUSHI_HIP_API int sushi_hip_fft_hop(void);
-SUSHI_HIP_API int64_t sushi_hip_spectra_blocks(int64_t n);
-SUSHI_HIP_API size_t sushi_hip_spectra_bytes(int64_t n);
+typedef struct SushiHipBatchInfo {
+    int32_t n_search;
+    int32_t path;
+    int32_t variant;          /* direct path: tile-size variant in use */
+    int32_t sub_batches;      /* FFT path: launches of each kernel per run (the batch is cut to fit the workspace) */
+    int64_t direct_tiles;
+    int64_t fft_pairs;        /* FFT path: block pairs (inverse transforms) of the whole batch */
+    int64_t fft_segments;     /* FFT path: pattern segments (forward transforms) of the whole batch */
+    uint64_t workspace_bytes; /* of mem_bytes: scratch reused by the sub-batches */
+    uint64_t mem_bytes;       /* what sushi_hip_batch_bytes returned */
+    double flops;             /* 2 * P * M summed over the requests (the direct form's work) */
+    double algorithmic_bytes; /* every search and pattern sample once + 8 bytes out per request */
+} SushiHipBatchInfo;
+
+typedef struct SushiHipBatchDiag {
+    int32_t flagged;          /* searches with more near-minimum positions than the per-pair / per-search lists hold */
+    int32_t all_positions;    /* of those: searches evaluated at every position (a candidate violated its error bound) */
+    int64_t tiles_dense;      /* 1024-position tiles evaluated exactly at every position */
+    int64_t tiles_sparse;     /* tiles evaluated exactly at listed candidate positions only */
+    int64_t candidates;       /* listed candidate positions */
+    float max_bound_ratio;    /* max over the exactly evaluated candidates of |f32 score - exact score| / the pair's
+                                 modelled error bound (without the delta/2 floor); < 1 or the search went to all_positions */
+    float reserved;
+} SushiHipBatchDiag;
+
+typedef struct SushiHipBatch SushiHipBatch;
+
+/* Bytes of device memory a batch of these requests needs: descriptors, schedules, result keys and a workspace of
+ * at most workspace_cap_bytes (0 = as much as one sub-batch for all requests needs; the minimum is what the most
+ * demanding single request needs -- the batch is cut into sub-batches that fit).  variant: -1 = choose. */
+SUSHI_HIP_API size_t sushi_hip_batch_bytes(const SushiHipRequest* req_host, int n, int path, int variant,
+                                           size_t workspace_cap_bytes);
+/* dst: the stream find_substream is called on (searchable for the FFT path); src: the stream the patterns are slices
+ * of (may be dst itself); same dtype.  Requests must lie inside their streams (EINVAL otherwise: the reference gets a
+ * cv2.error for a pattern longer than the window).  mem_dev: 256-byte aligned, >= sushi_hip_batch_bytes(...) with the
+ * same arguments.  The handle keeps pointers to dst and src: destroy it before them. */
+SUSHI_HIP_API int sushi_hip_batch_create(const SushiHipStream* dst, const SushiHipStream* src,
+                                         const SushiHipRequest* req_host, int n, int path, int variant,
+                                         size_t workspace_cap_bytes, void* mem_dev, size_t mem_bytes,
+                                         void* hip_stream, SushiHipBatch** out);
+SUSHI_HIP_API int sushi_hip_batch_info(const SushiHipBatch* batch, SushiHipBatchInfo* info);
+/* One pass of the hot path over the batch (asynchronous):
+ *   out_idx_dev[n]   = result.argmin(axis=1)[0]        (wav.py:186)
+ *   out_score_dev[n] = result[0][min_idx], float32     (wav.py:188)
+ * delta (FFT path; > 0, <= 1): floor of the score margin inside which positions are re-evaluated exactly -- every
+ * position whose f32 FFT score minus its error bound is not above the smallest (score plus bound) of the search.
+ * The bound of a pair is max(delta / 2, modelled f32 error); 2e-5 is the default of the Python layer. */
+SUSHI_HIP_API int sushi_hip_batch_run(SushiHipBatch* batch, double delta, int32_t* out_idx_dev, float* out_score_dev,
+                                      void* hip_stream);
+/* What the last run did (FFT path).  Waits for that run.  ranking_err_host (n floats or NULL): |f32 FFT score - exact
+ * score| at every request's result position (0 where a tile kernel found it); flagged_host (n int32 or NULL): 0 = the
+ * candidate list sufficed, 1 = tiles, 2 = every position. */
+SUSHI_HIP_API int sushi_hip_batch_diagnostics(SushiHipBatch* batch, SushiHipBatchDiag* diag, float* ranking_err_host,
+                                              int32_t* flagged_host);
+SUSHI_HIP_API void sushi_hip_batch_destroy(SushiHipBatch* batch);
+
+/* FFT path geometry of one request: block pairs (inverse transforms) and pattern segments (forward transforms). */
 SUSHI_HIP_API int sushi_hip_fft_layout(int64_t win_start, int32_t n_pos, int32_t tmpl_len,
                                        int32_t* n_pairs, int32_t* n_seg);
-/* Workspace needed to run n_search searches with n_pairs block pairs and n_seg template segments in
- * total as ONE sub-batch (the call splits a batch into sub-batches that fit the workspace it is given;
- * more workspace = fewer, larger launches; the minimum is what the largest single search needs). */
-SUSHI_HIP_API size_t sushi_hip_fft_workspace_bytes(int64_t n_pairs, int64_t n_seg, int64_t n_search);
 
-/* How many sub-batches sushi_hip_match_batch_fft cuts these searches into for a workspace of ws_bytes
- * (>= 1), or a negative SUSHI_HIP_E* code (ENOSPACE: some search does not fit on its own). */
-SUSHI_HIP_API int sushi_hip_fft_sub_batches(const SushiHipSearch* searches_host, int n_search, size_t ws_bytes);
-
-/* Optional L2-friendly schedule of the inverse-transform workgroups: order_host[total pairs of the batch]
- * receives, per sub-batch (as cut for a workspace of ws_bytes), a permutation of the sub-batch's pairs in
- * which pairs scoring the same region of the destination stream run back to back on one XCD.  Host-side,
- * computed once per batch; upload it and pass it as pair_order_dev (or pass NULL: workgroup = pair). */
-SUSHI_HIP_API int sushi_hip_fft_pair_order(const SushiHipSearch* searches_host, int n_search, size_t ws_bytes,
-                             int32_t* order_host, int64_t order_len);
-
-/* raw_dev: the stream's samples as they are (uint8 or float32, as given to sushi_hip_prepare_stream);
- * spec_dev: output (16-byte aligned). */
-SUSHI_HIP_API int sushi_hip_prepare_spectra(const void* raw_dev, int dtype, int64_t n, void* spec_dev, size_t spec_bytes,
-                                            void* hip_stream);
-
-/* Same results as sushi_hip_match_batch.  Additional arguments:
- *   dst_raw_dev / src_raw_dev / dtype : the two streams' samples as they were given to
- *                       sushi_hip_prepare_stream (template spectra and the exact refinement read them)
- *   dst_urel_dev / dst_base_dev : the relative window-energy prefix and its block bases of the dst stream
- *   dst_spec_dev      : sushi_hip_prepare_spectra output for the dst stream
- *   searches_host     : the same n_search descriptors in host memory (read during the call only);
- *                       first_tile must be laid out for variant sushi_hip_variant_count()-1,
- *                       first_pair / first_seg as running sums of sushi_hip_fft_layout()
- *   delta             : score margin, > 2x the error of the f32 FFT scores.  |d corr| <~ eps * |T| * |B|, B the
- *                       2*hop-sample blocks the window lies in: in score units a few float32 epsilons times
- *                       |B| / |window|.  For WavStream data (samples in [0,1] around the mid level) that ratio is
- *                       <= 2 * sqrt(max(1, 2*hop / tmpl_len)); patterns shorter than 2048 samples, where it
- *                       grows, are finished by the fallback kernel (flags_dev) whatever the FFT stage says.  2e-5 leaves a
- *                       margin of ~8x on BASELINE-shaped batches (measured per search: keys_ws_dev below)
- *   ws_dev / ws_bytes : scratch, >= sushi_hip_fft_workspace_bytes(pairs, segments, 1) of the largest search
- *   keys_ws_dev       : uint64[2 * n_search] scratch
- *   pair_order_dev    : int32[total pairs] from sushi_hip_fft_pair_order for the SAME ws_bytes, or NULL
- *   keys_ws_dev       : on completion the float32 at byte offset 8 * (n_search + k) is |FFT score - exact score|
- *                       of search k's result position (0 for searches finished by a fallback kernel): the
- *                       measured error of the ranking stage, to be compared with delta / 2
- *   flags_dev         : int32[2 * n_search + 2] scratch; on completion flags[k] = 1 if search k had too
- *                       many near-ties (or a pattern shorter than 2048 samples) and was finished by a fallback
- *                       kernel that evaluates every position: float32 streams exactly in float64 from the samples
- *                       themselves, uint8 streams by the MFMA kernel (exact on integers); flags[n_search] = how many */
-SUSHI_HIP_API int sushi_hip_match_batch_fft(const float* dst_xc_dev, const double* dst_s1_dev, const double* dst_s2_dev, int64_t dst_len,
-                              const float* dst_urel_dev, const double* dst_base_dev, const void* dst_spec_dev,
-                              const float* src_xc_dev, const double* src_s1_dev, const double* src_s2_dev, int64_t src_len,
-                              const void* dst_raw_dev, const void* src_raw_dev, int dtype, int method,
-                              const SushiHipSearch* searches_dev, const SushiHipSearch* searches_host,
-                              int n_search, double delta,
-                              void* ws_dev, size_t ws_bytes,
-                              uint64_t* keys_ws_dev, int32_t* flags_dev, const int32_t* pair_order_dev,
-                              int32_t* out_idx_dev, float* out_score_dev, void* hip_stream);
-
-/* ---- WavStream.__init__ value pipeline on the GPU (wav.py:113-156 after the host-side RIFF decode) ----
+/* ---- WavStream.__init__ on the GPU (wav.py:64-91 decode + downmix, wav.py:113-156 value pipeline) ----
+ * sushi_hip_load_decode   : interleaved little-endian PCM frames (sample_width 2 or 3 bytes, `channels` per frame)
+ *     -> float32 mono: the int16 (for 24-bit: the top two bytes, wav.py:70-74) of every channel converted to
+ *     float32, summed left to right in float32 and divided by float(channels) (wav.py:78-91).  Frames
+ *     [0, n_frames) of pcm_dev go to mono_dev[0 .. n_frames): callers upload and decode a file in bounded chunks.
  * sushi_hip_load_resample : data[pad + u] = nearest-neighbour decimation of the one-second chunks of the
  *     downmixed frames (cv2.resize INTER_NEAREST, wav.py:125-137: sx = min(floor(x * scale), chunk - 1) in
  *     float64), zeros where the reference never writes, and both pads filled with the nearest inner sample
@@ -201,6 +182,8 @@ SUSHI_HIP_API int sushi_hip_match_batch_fft(const float* dst_xc_dev, const doubl
  *     the building block of the exact radix select behind np.median(data[data >= 0]) (wav.py:145-146).
  * sushi_hip_load_normalise: in place clip to [lo, hi], subtract lo, divide by range (wav.py:148-151);
  *     if u8_dev != NULL also v * 255 + 0.5 truncated to uint8 (wav.py:153-156). */
+SUSHI_HIP_API int sushi_hip_load_decode(const void* pcm_dev, int64_t n_frames, int32_t channels, int32_t sample_width,
+                            float* mono_dev, void* hip_stream);
 SUSHI_HIP_API int sushi_hip_load_resample(const float* raw_dev, int64_t n_raw, int32_t chunk, int32_t nl_full, double scale_full,
                             int64_t n_full, int32_t rest, int32_t nl_rest, double scale_rest,
                             int64_t pad, int64_t total, float* data_dev, void* hip_stream);
@@ -209,16 +192,16 @@ SUSHI_HIP_API int sushi_hip_load_histogram(const float* data_dev, int64_t n, int
 SUSHI_HIP_API int sushi_hip_load_normalise(float* data_dev, int64_t n, float lo, float hi, float range, uint8_t* u8_dev,
                              void* hip_stream);
 
-/* Optional per-stage timing of sushi_hip_match_batch_fft with HIP events recorded on the launch
- * stream (bench.py's roofline figures).  Between _begin and _end every call records its stage
- * boundaries; _end waits for them and writes, per call, the milliseconds spent in each stage
- * (summed over the call's sub-batches) into stage_ms[call][SUSHI_HIP_NSTAGES].  Not thread safe. */
+/* Optional per-stage timing of the FFT path with HIP events recorded on the launch stream (bench.py's roofline
+ * figures).  Between _begin and _end every sushi_hip_batch_run records its stage boundaries; _end waits for them and
+ * writes, per run, the milliseconds spent in each stage (summed over the run's sub-batches) into
+ * stage_ms[run][SUSHI_HIP_NSTAGES].  Not thread safe. */
 #define SUSHI_HIP_NSTAGES 5
-#define SUSHI_HIP_STAGE_TSPEC 0    /* template-segment DFTs                          */
-#define SUSHI_HIP_STAGE_MAC 1      /* frequency-domain multiply-accumulate           */
-#define SUSHI_HIP_STAGE_IFFT 2     /* inverse DFTs + scoring epilogue                */
-#define SUSHI_HIP_STAGE_REFINE 3   /* exact float64 evaluation of the candidates     */
-#define SUSHI_HIP_STAGE_FINISH 4   /* direct-kernel fallback (if any) + unpack       */
+#define SUSHI_HIP_STAGE_TSPEC 0    /* pattern-segment DFTs                                          */
+#define SUSHI_HIP_STAGE_MAC 1      /* frequency-domain multiply-accumulate                          */
+#define SUSHI_HIP_STAGE_IFFT 2     /* inverse DFTs + scoring epilogue                               */
+#define SUSHI_HIP_STAGE_REFINE 3   /* exact float64 evaluation of the listed candidates             */
+#define SUSHI_HIP_STAGE_FINISH 4   /* candidate collection + exact tiles of flagged searches, unpack */
 SUSHI_HIP_API int sushi_hip_profile_begin(void);
 SUSHI_HIP_API int sushi_hip_profile_end(float* stage_ms, int max_calls, int* n_calls);
 

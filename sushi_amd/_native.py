@@ -14,21 +14,34 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SUSHI_HIP_LIB") or os.path.join(_HERE, "lib", "libsushi_hip.so")   # env: dev A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sushi_hip.h")
 
-# dtype codes (include/sushi_hip.h)
+# dtype codes / paths (include/sushi_hip.h)
 U8, F32 = 0, 1
-SQDIFF_NORMED = 0
+PATH_FFT, PATH_DIRECT = 0, 1
+VIEW_XC, VIEW_S1, VIEW_S2, VIEW_UREL, VIEW_BASE, VIEW_SPECTRA = range(6)
 
 ABI_VERSION = 5
 NSTAGES = 5
 STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish")
 STAGE_KERNELS = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "ifft_kernel", "refine": "refine_kernel",
-                 "finish": "exact_flagged_kernel|match_flagged_kernel+unpack_keys_kernel"}
+                 "finish": "collect_kernel+exact_tiles_kernel+unpack_keys_kernel"}
 
-# struct SushiHipSearch, 40 bytes
-SEARCH_DTYPE = np.dtype([("tmpl_off", "<i8"), ("win_start", "<i8"), ("tmpl_len", "<i4"),
-                         ("n_pos", "<i4"), ("first_tile", "<i4"), ("first_pair", "<i4"),
-                         ("first_seg", "<i4"), ("reserved", "<i4")], align=True)
-assert SEARCH_DTYPE.itemsize == 40
+# struct SushiHipRequest, 24 bytes
+REQUEST_DTYPE = np.dtype([("tmpl_off", "<i8"), ("win_start", "<i8"), ("tmpl_len", "<i4"), ("n_pos", "<i4")], align=True)
+assert REQUEST_DTYPE.itemsize == 24
+
+
+class BatchInfo(ctypes.Structure):
+    _fields_ = [("n_search", ctypes.c_int32), ("path", ctypes.c_int32), ("variant", ctypes.c_int32),
+                ("sub_batches", ctypes.c_int32), ("direct_tiles", ctypes.c_int64), ("fft_pairs", ctypes.c_int64),
+                ("fft_segments", ctypes.c_int64), ("workspace_bytes", ctypes.c_uint64), ("mem_bytes", ctypes.c_uint64),
+                ("flops", ctypes.c_double), ("algorithmic_bytes", ctypes.c_double)]
+
+
+class BatchDiag(ctypes.Structure):
+    _fields_ = [("flagged", ctypes.c_int32), ("all_positions", ctypes.c_int32), ("tiles_dense", ctypes.c_int64),
+                ("tiles_sparse", ctypes.c_int64), ("candidates", ctypes.c_int64), ("max_bound_ratio", ctypes.c_float),
+                ("reserved", ctypes.c_float)]
+
 
 _lib = None
 
@@ -57,41 +70,44 @@ def lib():
     import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, i64, ci, dbl, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+    i32, u32, cf = ctypes.c_int32, ctypes.c_uint32, ctypes.c_float
+    pvp = ctypes.POINTER(vp)
     L.sushi_hip_abi_version.restype = ci
     L.sushi_hip_strerror.restype = ctypes.c_char_p
     L.sushi_hip_strerror.argtypes = [ci]
     L.sushi_hip_device_ok.restype = ci
-    L.sushi_hip_variant_count.restype = ci
-    L.sushi_hip_variant_tile_positions.restype = ci
-    L.sushi_hip_variant_tile_positions.argtypes = [ci]
-    L.sushi_hip_prepare_base_bytes.restype = sz
-    L.sushi_hip_prepare_base_bytes.argtypes = [i64]
+    L.sushi_hip_fft_size.restype = ci
+    L.sushi_hip_fft_block.restype = ci
     L.sushi_hip_centre.restype = dbl
     L.sushi_hip_centre.argtypes = [ci]
-    L.sushi_hip_prepare_stream.restype = ci
-    L.sushi_hip_prepare_stream.argtypes = [vp, ci, i64, vp, vp, vp, vp, vp, sz, vp]
-    L.sushi_hip_match_batch.restype = ci
-    L.sushi_hip_match_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp, i64, dbl, ci, vp, ci, ci, ci, vp, vp, vp, vp]
-    i32 = ctypes.c_int32
-    L.sushi_hip_fft_hop.restype = ci
-    L.sushi_hip_spectra_blocks.restype = i64
-    L.sushi_hip_spectra_blocks.argtypes = [i64]
-    L.sushi_hip_spectra_bytes.restype = sz
-    L.sushi_hip_spectra_bytes.argtypes = [i64]
+    L.sushi_hip_stream_bytes.restype = sz
+    L.sushi_hip_stream_bytes.argtypes = [i64, ci, ci]
+    L.sushi_hip_stream_spectra_bytes.restype = sz
+    L.sushi_hip_stream_spectra_bytes.argtypes = [i64]
+    L.sushi_hip_stream_create.restype = ci
+    L.sushi_hip_stream_create.argtypes = [vp, ci, i64, ci, vp, sz, vp, pvp]
+    L.sushi_hip_stream_add_spectra.restype = ci
+    L.sushi_hip_stream_add_spectra.argtypes = [vp, vp, sz, vp]
+    L.sushi_hip_stream_view.restype = ci
+    L.sushi_hip_stream_view.argtypes = [vp, ci, pvp, ctypes.POINTER(sz)]
+    L.sushi_hip_stream_destroy.restype = None
+    L.sushi_hip_stream_destroy.argtypes = [vp]
+    L.sushi_hip_batch_bytes.restype = sz
+    L.sushi_hip_batch_bytes.argtypes = [vp, ci, ci, ci, sz]
+    L.sushi_hip_batch_create.restype = ci
+    L.sushi_hip_batch_create.argtypes = [vp, vp, vp, ci, ci, ci, sz, vp, sz, vp, pvp]
+    L.sushi_hip_batch_info.restype = ci
+    L.sushi_hip_batch_info.argtypes = [vp, ctypes.POINTER(BatchInfo)]
+    L.sushi_hip_batch_run.restype = ci
+    L.sushi_hip_batch_run.argtypes = [vp, dbl, vp, vp, vp]
+    L.sushi_hip_batch_diagnostics.restype = ci
+    L.sushi_hip_batch_diagnostics.argtypes = [vp, ctypes.POINTER(BatchDiag), vp, vp]
+    L.sushi_hip_batch_destroy.restype = None
+    L.sushi_hip_batch_destroy.argtypes = [vp]
     L.sushi_hip_fft_layout.restype = ci
     L.sushi_hip_fft_layout.argtypes = [i64, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
-    L.sushi_hip_fft_workspace_bytes.restype = sz
-    L.sushi_hip_fft_workspace_bytes.argtypes = [i64, i64, i64]
-    L.sushi_hip_prepare_spectra.restype = ci
-    L.sushi_hip_prepare_spectra.argtypes = [vp, ci, i64, vp, sz, vp]
-    L.sushi_hip_match_batch_fft.restype = ci
-    L.sushi_hip_match_batch_fft.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, ci, ci, vp, vp, ci, dbl,
-                                            vp, sz, vp, vp, vp, vp, vp, vp]
-    L.sushi_hip_fft_sub_batches.restype = ci
-    L.sushi_hip_fft_sub_batches.argtypes = [vp, ci, sz]
-    L.sushi_hip_fft_pair_order.restype = ci
-    L.sushi_hip_fft_pair_order.argtypes = [vp, ci, sz, vp, i64]
-    u32, cf = ctypes.c_uint32, ctypes.c_float
+    L.sushi_hip_load_decode.restype = ci
+    L.sushi_hip_load_decode.argtypes = [vp, i64, i32, i32, vp, vp]
     L.sushi_hip_load_resample.restype = ci
     L.sushi_hip_load_resample.argtypes = [vp, i64, i32, i32, dbl, i64, i32, i32, dbl, i64, i64, vp, vp]
     L.sushi_hip_load_histogram.restype = ci
@@ -113,21 +129,12 @@ def check(rc, what):
         raise NativeError("%s failed: %s (%d)" % (what, msg, rc))
 
 
-def variant_tiles():
-    L = lib()
-    return [L.sushi_hip_variant_tile_positions(v) for v in range(L.sushi_hip_variant_count())]
-
-
 def fft_layout(win_start, n_pos, tmpl_len):
-    """Vectorised twin of sushi_hip_fft_layout (csrc/sushi_common.hpp fft_layout): block pairs and
-    template segments per search.  sushi_hip_match_batch_fft re-derives and checks the running sums."""
-    hop = lib().sushi_hip_fft_hop()
-    w = np.asarray(win_start, dtype=np.int64)
-    p = np.asarray(n_pos, dtype=np.int64)
-    m = np.asarray(tmpl_len, dtype=np.int64)
-    k0 = w // hop
-    kl = (w + p - 1) // hop
-    return (kl - k0 + 2) // 2, (m + hop - 1) // hop
+    """(block pairs, pattern segments) of one request on the FFT path (sushi_hip_fft_layout)."""
+    a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+    check(lib().sushi_hip_fft_layout(int(win_start), int(n_pos), int(tmpl_len), ctypes.byref(a), ctypes.byref(b)),
+          "sushi_hip_fft_layout")
+    return a.value, b.value
 
 
 def profile_begin():

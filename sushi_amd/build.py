@@ -16,7 +16,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "sushi_hip.h")
 LIB_DIR = os.path.join(_HERE, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB = os.path.join(LIB_DIR, "libsushi_hip.so")
-TWIDDLE_INC = os.path.join(CSRC, "_gen_twiddle8192.inc")
+TWIDDLE_INC = os.path.join(CSRC, "_gen_twiddle16384.inc")
 
 COMMON_DEPS = [HEADER, os.path.join(CSRC, "sushi_common.hpp"), os.path.join(CSRC, "sushi_internal.hpp")]
 # -ffp-contract=off for sushi_hip.hip: its float64 epilogue restates cv2's operation order; a fused
@@ -38,7 +38,7 @@ def _hipcc():
     raise RuntimeError("hipcc not found (need ROCm to build libsushi_hip.so)")
 
 
-def write_twiddles(n=8192):
+def write_twiddles(n=16384):
     """exp(-2*pi*i*k/n) as float32 literals (interleaved re, im), correctly rounded from float64."""
     import numpy as np
     k = np.arange(n, dtype=np.float64)
@@ -69,18 +69,21 @@ def needs_build():
     return _stale(LIB, deps)
 
 
-def build_native(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -O3 -c csrc/*.hip -> lib/obj/*.o -> lib/libsushi_hip.so"""
+def build_native(force=False, verbose=False, defines=(), lib=None, obj_tag=""):
+    """hipcc --offload-arch=gfx950 -O3 -c csrc/*.hip -> lib/obj/*.o -> lib/libsushi_hip.so
+    `defines` / `lib` / `obj_tag`: a variant library beside the product one (tools/ A/B measurements), e.g.
+    defines=("-DSUSHI_FFT_LOGN=13",), lib=".../libsushi_hip_n13.so", obj_tag="_n13"."""
     write_twiddles()
-    if not force and not needs_build():
-        return LIB
+    lib = lib or LIB
+    if not force and not defines and not needs_build():
+        return lib
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
-    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall"]
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall"] + list(defines)
     objs, procs = [], []
     for name, flags, extra in UNITS:
         src = os.path.join(CSRC, name + ".hip")
-        obj = os.path.join(OBJ_DIR, name + ".o")
+        obj = os.path.join(OBJ_DIR, name + obj_tag + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + COMMON_DEPS + extra):
             cmd = base + flags + ["-c", src, "-o", obj]
@@ -90,11 +93,11 @@ def build_native(force=False, verbose=False):
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-o", lib]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -10,12 +10,30 @@
 
 namespace sushi {
 
-constexpr int FFT_HOP = 4096;            // result positions per overlap-save block (= fft_core N / 2)
-constexpr int FFT_CAND = 8;              // candidate slots per block pair (+1 truncation marker)
-// Patterns shorter than this are finished by the fallback kernel (every position evaluated): the float32 error of an FFT'd cross term is
-// relative to |T| * |the whole 2*FFT_HOP-sample block|, not to |T| * |the window|, so for M samples it is
-// ~sqrt(2 * FFT_HOP / M) times larger in score units than the `delta` margin was measured for.
-constexpr int FFT_MIN_TMPL = 2048;
+// ---- overlap-save geometry ------------------------------------------------------------
+// Transform length N = 2^FFT_LOGN complex points; patterns are cut into segments of FFT_SEG samples, so a real
+// block of N samples yields FFT_H = N - FFT_SEG valid positions; two real blocks FFT_H apart are packed into one
+// complex block (a "pair": 2 * FFT_H positions per transform).  Spectra are kept at every multiple of FFT_SEG
+// ("block" j = samples from j * FFT_SEG on); consecutive pairs of a search are FFT_STEP blocks apart.
+#ifndef SUSHI_FFT_LOGN
+#define SUSHI_FFT_LOGN 14
+#endif
+constexpr int FFT_LOGN = SUSHI_FFT_LOGN;
+constexpr int FFT_N = 1 << FFT_LOGN;
+constexpr int FFT_SEG = 4096;
+constexpr int FFT_HOP = FFT_SEG;                   // also the block size of the relative window-energy prefix (urel / base)
+constexpr int FFT_VB = FFT_N / FFT_SEG - 1;        // valid blocks per half of a pair: 1 (N = 8192) or 3 (N = 16384)
+constexpr int FFT_H = FFT_VB * FFT_SEG;            // result positions per half
+constexpr int FFT_STEP = 2 * FFT_VB;               // blocks between consecutive pairs
+constexpr int FFT_CAND = 8;                        // candidate slots per block pair (+ overflow marker + error bound)
+constexpr int FFT_ROW = FFT_CAND + 2;              // 64-bit entries per pair in the candidate array
+constexpr int TILE = 1024;                         // positions per exact-evaluation tile (aligned to the absolute grid)
+constexpr int TILES_PER_PAIR = 2 * FFT_H / TILE;
+// error model of the f32 FFT stage: |corr_f32 - corr| <= FFT_KE * 2^-24 * |T| * |Z|, Z = the samples that enter the
+// pair's transforms (n_seg + 2 * FFT_VB blocks).  Calibrated: the largest ratio measured over the parity and property
+// tests is recorded by refine_kernel (diagnostics) and stays below FFT_KE / 3; a candidate whose exact score
+// violates its bound sends the whole search to exact evaluation.
+constexpr float FFT_KE = 32.0f;
 constexpr unsigned long long NO_KEY = ~0ull;
 
 // XCD-aware remap (MI355X: block b runs on XCD b % 8): give every XCD a contiguous run of
@@ -128,15 +146,26 @@ __device__ __forceinline__ float score_exact(double corr_u, const TemplStats& t,
     return finish_sqdiff_normed(corr_u, w2[p + M] - w2[p], t.tU, t.tnorm);
 }
 
-// Overlap-save layout of one search (DESIGN.md "FFT path"); the host twin is sushi_hip_fft_layout().
-struct FftLayout { int64_t k0; int n_pairs; int n_seg; };
+// Overlap-save layout of one search (DESIGN.md "FFT path"): its block pairs sit on the ABSOLUTE pair grid (pair I
+// starts at block FFT_STEP * I), from the pair holding the window's first position to the one holding its last.
+struct FftLayout { int64_t pair0; int n_pairs; int n_seg; };
 __host__ __device__ inline FftLayout fft_layout(int64_t win_start, int n_pos, int tmpl_len) {
     FftLayout l;
-    l.k0 = win_start / FFT_HOP;
-    const int64_t kl = (win_start + n_pos - 1) / FFT_HOP;
-    l.n_pairs = (int)((kl - l.k0 + 2) / 2);
-    l.n_seg = (tmpl_len + FFT_HOP - 1) / FFT_HOP;
+    l.pair0 = (win_start / FFT_SEG) / FFT_STEP;
+    const int64_t pair_last = ((win_start + n_pos - 1) / FFT_SEG) / FFT_STEP;
+    l.n_pairs = (int)(pair_last - l.pair0 + 1);
+    l.n_seg = (tmpl_len + FFT_SEG - 1) / FFT_SEG;
     return l;
+}
+
+// segment-count class of a search: the smallest SMAX (a multiple of FFT_STEP) that holds the whole pattern;
+// longer patterns use the largest class and several chunks
+constexpr int MAC_CLASSES = FFT_STEP == 2 ? 4 : 3;
+__host__ __device__ inline int mac_class_smax(int c) { return FFT_STEP == 2 ? 4 * (c + 1) : 6 * (c + 1); }
+__host__ __device__ inline int mac_class(int n_seg) {
+    for (int c = 0; c < MAC_CLASSES - 1; ++c)
+        if (n_seg <= mac_class_smax(c)) return c;
+    return MAC_CLASSES - 1;
 }
 
 }  // namespace sushi

@@ -28,6 +28,8 @@
 #include <stdint.h>
 #include <float.h>
 
+#include <new>
+
 #include "../../include/sushi_hip.h"
 #include "sushi_common.hpp"
 #include "sushi_internal.hpp"
@@ -54,7 +56,7 @@ struct MatchArgs {
     const double* src_s2;
     int64_t src_len;
     double centre;
-    const SushiHipSearch* searches;
+    const SearchDesc* searches;
     int n_search;
     int n_tiles;
     unsigned long long* keys;
@@ -69,7 +71,7 @@ template <int WAVES, int NB> struct TileShape {
 
 // One tile (TP consecutive result positions) of one search.  `lds` holds LDS_FLOATS floats, `red` WAVES keys.
 template <int WAVES, int NB>
-__device__ __forceinline__ void match_tile(const MatchArgs& a, const int s_idx, const SushiHipSearch sd,
+__device__ __forceinline__ void match_tile(const MatchArgs& a, const int s_idx, const SearchDesc sd,
                                            const int tile_in_search, float* lds, unsigned long long* red) {
     constexpr int NT = TileShape<WAVES, NB>::NT;
     constexpr int TP = TileShape<WAVES, NB>::TP;
@@ -223,122 +225,111 @@ void match_sqdiff_f32_kernel(MatchArgs a) {
         const int mid = (lo + hi + 1) >> 1;
         if (a.searches[mid].first_tile <= tile) lo = mid; else hi = mid - 1;
     }
-    const SushiHipSearch sd = a.searches[lo];
+    const SearchDesc sd = a.searches[lo];
     match_tile<WAVES, NB>(a, lo, sd, tile - sd.first_tile, lds, red);
 }
 
-// Fallback of the FFT path: the same tiles, only for the searches the refinement flagged
-// (flags[n_search] = how many, flags[n_search + 2 ..] = which).  Fixed grid, workgroups stride over
-// the (flagged search, tile) work items; with nothing flagged every workgroup leaves after one load.
-template <int WAVES, int NB>
-__global__ __launch_bounds__(WAVES * 64, 2)
-void match_flagged_kernel(MatchArgs a, const int* __restrict__ flags) {
-    __shared__ __attribute__((aligned(16))) float lds[TileShape<WAVES, NB>::LDS_FLOATS];
-    __shared__ unsigned long long red[WAVES];
-    constexpr int TP = TileShape<WAVES, NB>::TP;
-    const int n_flagged = flags[a.n_search];
-    if (n_flagged == 0) return;
-    const int* __restrict__ list = flags + a.n_search + 2;
-    for (int v = blockIdx.x;; v += gridDim.x) {
-        int acc = 0, found = -1, tin = 0;
-        for (int f = 0; f < n_flagged; ++f) {
-            const int s = list[f];
-            const int nt = (a.searches[s].n_pos + TP - 1) / TP;
-            if (v < acc + nt) { found = s; tin = v - acc; break; }
-            acc += nt;
-        }
-        if (found < 0) break;
-        match_tile<WAVES, NB>(a, found, a.searches[found], tin, lds, red);
-        __syncthreads();
-    }
+// ------------------------------------------------------------------------------------------
+// FFT path, exact stages.  One accumulation order everywhere (refine_kernel, both modes of exact_tiles_kernel):
+// sum T*I over the samples as they are, in float64 (every product of two float32 or uint8 values is exact there),
+// XM pattern samples at a time -- each chunk summed sequentially from 0 with one fused multiply-add per sample,
+// the chunk sums added in order.  The value of a position therefore does not depend on which kernel, which tile
+// or which window evaluated it.
+// ------------------------------------------------------------------------------------------
+constexpr int XT = TILE;         // positions per tile
+constexpr int XM = 512;          // pattern samples per chunk of the canonical sum
+static_assert(XT == 1024 && XM % 4 == 0, "exact_tiles_kernel: 256 threads x 4 consecutive positions, steps of 4 samples");
+
+template <typename T>
+__device__ __forceinline__ double chunk_dot(const T* __restrict__ t, const T* __restrict__ w, int mc) {
+    double acc = 0.0;
+    for (int m = 0; m < mc; ++m) acc = __builtin_fma((double)t[m], (double)w[m], acc);
+    return acc;
 }
 
-// The same job for float32 streams, exactly: sum T*I in float64 over the samples as they are (every product of
-// two float32 values is exact in float64), cv2's epilogue from the float64 prefix sums -- what refine_kernel does
-// for a handful of positions, here for every position of the flagged searches.  ~3x the time of the MFMA kernel,
-// independent of where the data sit (the MFMA kernel's contract is the mid-level one, include/sushi_hip.h).
-// A work item = XT positions of one flagged search; the pattern is staged XM samples at a time.  34 TFLOP/s of f64.
-constexpr int XT = 1024;
-constexpr int XM = 512;
-
-struct ExactArgs {
-    StreamRefs r;
-    const SushiHipSearch* searches;
-    int n_search;
-    unsigned long long* keys;
-};
-
+// Exact evaluation of the tiles collect_kernel listed: every valid position of a dense tile (a thread owns four
+// CONSECUTIVE positions: the pattern samples T[m .. m+3] then meet the seven search samples I[p .. p+6], of which
+// four are the previous step's -- one 16-byte LDS read of each per 16 float64 FMAs), or the listed candidate
+// positions of a sparse tile (one per thread).  Fixed grid, workgroups stride over the tile list; with no tile
+// listed every workgroup leaves after one load.
+template <typename T>
 __global__ __launch_bounds__(256)
-void exact_flagged_kernel(ExactArgs a, const int* __restrict__ flags) {
-    // a thread owns XQ = 4 CONSECUTIVE positions: the pattern samples T[m .. m+3] then meet the seven search samples
-    // I[p .. p+6], of which four are the previous step's -- one 16-byte LDS read of each per 16 float64 FMAs
+void exact_tiles_kernel(TileParams a) {
     constexpr int XQ = XT / 256;
-    static_assert(XQ == 4 && XM % 4 == 0, "the inner loop is written for four positions and four pattern samples a step");
     __shared__ __attribute__((aligned(16))) float lt[XM];
     __shared__ __attribute__((aligned(16))) float li[XT + XM];
     __shared__ unsigned long long red[4];
-    const int n_flagged = flags[a.n_search];
-    if (n_flagged == 0) return;
-    const int* __restrict__ list = flags + a.n_search + 2;
+    const int n_tiles = a.counters->n_tiles;
+    if (n_tiles == 0) return;
     const int tid = threadIdx.x;
-    for (int v = blockIdx.x;; v += gridDim.x) {
-        int acc_items = 0, found = -1, tin = 0;
-        for (int f = 0; f < n_flagged; ++f) {
-            const int s = list[f];
-            const int nt = (a.searches[s].n_pos + XT - 1) / XT;
-            if (v < acc_items + nt) { found = s; tin = v - acc_items; break; }
-            acc_items += nt;
-        }
-        if (found < 0) break;
-        const SushiHipSearch sd = a.searches[found];
+    for (int v = blockIdx.x; v < n_tiles; v += gridDim.x) {
+        const TileDesc td = a.tiles[v];
+        const SearchDesc sd = a.searches[td.search];
         const int M = sd.tmpl_len;
-        const int p0 = tin * XT;                                        // first position of this item
-        const float* __restrict__ T = (const float*)a.r.src_raw + sd.tmpl_off;
-        const float* __restrict__ I = (const float*)a.r.dst_raw + sd.win_start + p0;
-        const int64_t room = a.r.dst_len - (sd.win_start + p0);        // samples of the stream from I on
-        double acc[XQ] = {0.0, 0.0, 0.0, 0.0};
+        const int p0 = td.p0;                                           // may be negative: tiles sit on the absolute grid
+        const bool dense = td.cnt < 0;
+        const T* __restrict__ Tp = (const T*)a.r.src_raw + sd.tmpl_off;
+        const T* __restrict__ Ip = (const T*)a.r.dst_raw + (sd.win_start + p0);
+        const int64_t room = a.r.dst_len - (sd.win_start + p0);         // samples of the stream from Ip on
+        int mine = -1;                                                  // sparse: this thread's candidate, relative to p0
+        if (!dense && tid < td.cnt) mine = a.cand[td.off + tid] - p0;
+        double tot[XQ] = {0.0, 0.0, 0.0, 0.0};
         for (int m0 = 0; m0 < M; m0 += XM) {
             const int mc = min(XM, M - m0);
-            for (int e = tid; e < XM; e += 256) lt[e] = e < mc ? T[m0 + e] : 0.f;      // zero padded: whole steps of 4
-            for (int e = tid; e < XT + XM; e += 256) li[e] = (int64_t)m0 + e < room ? I[m0 + e] : 0.f;
+            __syncthreads();                                            // previous chunk's (or tile's) reads are done
+            for (int e = tid; e < XM; e += 256) lt[e] = e < mc ? (float)Tp[m0 + e] : 0.f;      // zero padded: whole steps of 4
+            for (int e = tid; e < XT + XM; e += 256) li[e] = (int64_t)m0 + e < room ? (float)Ip[m0 + e] : 0.f;
             __syncthreads();
-            const float4* __restrict__ li4 = reinterpret_cast<const float4*>(li) + tid;   // li[4 tid + 4 k ..]
-            const float4* __restrict__ lt4 = reinterpret_cast<const float4*>(lt);
-            float4 lo = li4[0];
-            for (int k = 0; k < (mc + 3) / 4; ++k) {
-                const float4 hi = li4[k + 1];
-                const float4 t4 = lt4[k];
-                const double w[8] = {(double)lo.x, (double)lo.y, (double)lo.z, (double)lo.w,
-                                     (double)hi.x, (double)hi.y, (double)hi.z, (double)hi.w};
-                const double t[4] = {(double)t4.x, (double)t4.y, (double)t4.z, (double)t4.w};
+            if (dense) {
+                const float4* __restrict__ li4 = reinterpret_cast<const float4*>(li) + tid;   // li[4 tid + 4 k ..]
+                const float4* __restrict__ lt4 = reinterpret_cast<const float4*>(lt);
+                double acc[XQ] = {0.0, 0.0, 0.0, 0.0};
+                float4 lo = li4[0];
+                for (int k = 0; k < (mc + 3) / 4; ++k) {
+                    const float4 hi = li4[k + 1];
+                    const float4 t4 = lt4[k];
+                    const double w[8] = {(double)lo.x, (double)lo.y, (double)lo.z, (double)lo.w,
+                                         (double)hi.x, (double)hi.y, (double)hi.z, (double)hi.w};
+                    const double t[4] = {(double)t4.x, (double)t4.y, (double)t4.z, (double)t4.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {                          // pattern samples in order: one accumulation order per position
+                    for (int j = 0; j < 4; ++j) {                          // pattern samples in order (padding adds exact zeros)
 #pragma unroll
-                    for (int q = 0; q < XQ; ++q) acc[q] = __builtin_fma(t[j], w[q + j], acc[q]);
+                        for (int q = 0; q < XQ; ++q) acc[q] = __builtin_fma(t[j], w[q + j], acc[q]);
+                    }
+                    lo = hi;
                 }
-                lo = hi;
+#pragma unroll
+                for (int q = 0; q < XQ; ++q) tot[q] += acc[q];
+            } else if (mine >= 0) {
+                const float* __restrict__ wv = li + mine;
+                double acc = 0.0;
+                for (int m = 0; m < mc; ++m) acc = __builtin_fma((double)lt[m], (double)wv[m], acc);
+                tot[0] += acc;
             }
-            __syncthreads();
         }
         const TemplStats ts = templ_stats(a.r.src_s1, a.r.src_s2, sd.tmpl_off, M, a.r.centre);
         const double* __restrict__ w2 = a.r.dst_s2 + sd.win_start;
         unsigned long long best = NO_KEY;
+        if (dense) {
 #pragma unroll
-        for (int q = 0; q < XQ; ++q) {
-            const int p = p0 + XQ * tid + q;
-            if (p < sd.n_pos) {
-                const unsigned long long key = make_key(score_exact(acc[q], ts, w2, (int64_t)p, M), (unsigned)p);
-                best = key < best ? key : best;
+            for (int q = 0; q < XQ; ++q) {
+                const int p = p0 + XQ * tid + q;
+                if (p >= 0 && p < sd.n_pos) {
+                    const unsigned long long key = make_key(score_exact(tot[q], ts, w2, (int64_t)p, M), (unsigned)p);
+                    best = key < best ? key : best;
+                }
             }
+        } else if (mine >= 0) {
+            const int p = p0 + mine;
+            best = make_key(score_exact(tot[0], ts, w2, (int64_t)p, M), (unsigned)p);
         }
         best = wave_min_u64(best);
         if ((tid & 63) == 0) red[tid >> 6] = best;
         __syncthreads();
         if (tid == 0) {
             for (int w = 1; w < 4; ++w) best = red[w] < best ? red[w] : best;
-            if (best != NO_KEY) atomicMin(a.keys + found, best);
+            if (best != NO_KEY) atomicMin(a.keys + td.search, best);
         }
-        __syncthreads();
     }
 }
 
@@ -353,103 +344,142 @@ __global__ void unpack_keys_kernel(const unsigned long long* __restrict__ keys, 
 }
 
 // ------------------------------------------------------------------------------------------
-// FFT path, last stage: every position whose f32 FFT score is within `delta` of the search's
-// minimum is re-evaluated exactly (float64 sum of the exact f32*f32 products, float64 prefix
-// sums, cv2's epilogue); the arg-min over those is the result.  One workgroup per search.
-// A search with more than RCAP such positions, or with a block pair that could not list all of
-// its own, is flagged for the fallback kernels (launch_flagged) instead.
+// FFT path: the candidates ifft_kernel listed per pair.  A position is a candidate of the search if its lower
+// bound (f32 score - the pair's error bound) is not above the search's threshold U = the smallest (f32 score +
+// bound) over all pairs: the exact minimum cannot lie anywhere else.  Up to RCAP candidates are evaluated here,
+// exactly; a search with more, or with a pair that could not list all of its own, is flagged for the
+// collection pass + exact_tiles_kernel (flag 1).  Every evaluated candidate also checks the bound it was selected
+// with: an exact score further from the f32 one than the bound allows means the error model does not hold for this
+// search, which is then evaluated at every position (flag 2).  One workgroup per search.
 // ------------------------------------------------------------------------------------------
 constexpr int RCAP = 128;
 
-struct RefineArgs {
-    StreamRefs r;
-    const SushiHipSearch* searches;
-    int first_search;
-    int sub_first_pair;
-    const unsigned long long* cand;
-    unsigned long long* gkeys;        // in: minimum of the f32 FFT scores; out: |f32 - exact| of the result (float bits)
-    float delta;
-    unsigned long long* keys;
-    int* flags;
-    int n_search;
-};
-
-__global__ __launch_bounds__(256)
-void refine_kernel(RefineArgs a) {
-    __shared__ unsigned long long list[RCAP];
-    __shared__ int cnt, ovf;
-    __shared__ double part[4];
+template <typename T>
+__device__ __forceinline__ void refine_body(const RefineParams& a, const int s_idx, const SearchDesc& sd,
+                                            const unsigned long long* list, const int* lpair,
+                                            const unsigned long long* rows, const int n, double* part,
+                                            unsigned long long* rkey, float* rerr, int* violated) {
     const int tid = threadIdx.x;
-    const int s_idx = a.first_search + blockIdx.x;
-    const SushiHipSearch sd = a.searches[s_idx];
-    const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
-    if (tid == 0) { cnt = 0; ovf = sd.tmpl_len < FFT_MIN_TMPL ? 1 : 0; }      // short patterns: the fallback kernels'
-    __syncthreads();
-    const float thr = key_score(a.gkeys[s_idx]) + a.delta;
-    const unsigned long long* __restrict__ c = a.cand + (size_t)(sd.first_pair - a.sub_first_pair) * (FFT_CAND + 1);
-    const int n_ent = lay.n_pairs * (FFT_CAND + 1);
-    for (int e = tid; e < n_ent; e += 256) {
-        const unsigned long long key = c[e];
-        if (key != NO_KEY && key_score(key) <= thr) {
-            if (key_pos(key) >= 0xfffffffeu) {
-                ovf = 1;                                   // that pair had more near-minimum positions than slots, or
-                                                           // declared its f32 scores untrustworthy (ifft_kernel)
-            } else {
-                const int slot = atomicAdd(&cnt, 1);
-                if (slot < RCAP) list[slot] = key; else ovf = 1;
-            }
-        }
-    }
-    __syncthreads();
-    if (ovf) {
-        if (tid == 0) {
-            a.flags[s_idx] = 1;
-            const int k = atomicAdd(a.flags + a.n_search, 1);
-            a.flags[a.n_search + 2 + k] = s_idx;
-            a.gkeys[s_idx] = 0ull;
-        }
-        return;                                            // keys[s_idx] stays NO_KEY for the fallback kernel
-    }
-    const int n = cnt;
     const int M = sd.tmpl_len;
+    const int n_chunks = (M + XM - 1) / XM;
+    const T* __restrict__ Tp = (const T*)a.r.src_raw + sd.tmpl_off;
+    const T* __restrict__ Wp = (const T*)a.r.dst_raw + sd.win_start;
     const TemplStats ts = templ_stats(a.r.src_s1, a.r.src_s2, sd.tmpl_off, M, a.r.centre);
     const double* __restrict__ w2 = a.r.dst_s2 + sd.win_start;
-    unsigned long long best = NO_KEY;
-    float best_approx = 0.f;
-    for (int k = 0; k < n; ++k) {
+    auto finish = [&](const int k, const double corr_u) {
         const unsigned p = key_pos(list[k]);
-        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-        // sum T*I over the samples as they are: products of two float32 (or uint8) values are exact in float64
-        auto dot = [&](auto src, auto d) {
-            int m = tid;
-            for (; m + 768 < M; m += 1024) {
-                acc0 += (double)src[m] * (double)d[m];
-                acc1 += (double)src[m + 256] * (double)d[m + 256];
-                acc2 += (double)src[m + 512] * (double)d[m + 512];
-                acc3 += (double)src[m + 768] * (double)d[m + 768];
-            }
-            for (; m < M; m += 256) acc0 += (double)src[m] * (double)d[m];
-        };
-        if (a.r.dtype == SUSHI_HIP_F32)
-            dot((const float*)a.r.src_raw + sd.tmpl_off, (const float*)a.r.dst_raw + sd.win_start + p);
-        else
-            dot((const uint8_t*)a.r.src_raw + sd.tmpl_off, (const uint8_t*)a.r.dst_raw + sd.win_start + p);
-        double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
-        if ((tid & 63) == 0) part[tid >> 6] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            const double corr_u = (part[0] + part[1]) + (part[2] + part[3]);
-            const float score = score_exact(corr_u, ts, w2, (int64_t)p, M);
-            const unsigned long long key = make_key(score, p);
-            if (key < best) { best = key; best_approx = key_score(list[k]); }
+        const float score = score_exact(corr_u, ts, w2, (int64_t)p, M);
+        rkey[k] = make_key(score, p);
+        const unsigned long long eb = rows[(size_t)lpair[k] * FFT_ROW + FFT_CAND + 1];
+        const float e_pair = __uint_as_float((unsigned)(eb & 0xffffffffull));
+        const float e_model = __uint_as_float((unsigned)(eb >> 32));
+        const float lb = key_score(list[k]);
+        float err = 0.f;
+        if (lb > 0.f) {                                         // the f32 score itself (a bound clamped at 0 lost it)
+            err = fabsf((lb + e_pair) - score);
+            if (err > e_pair * 1.001f + 1e-7f) *violated = 1;
+            if (e_model > 0.f) atomicMax(&a.counters->max_ratio_bits, __float_as_uint(err / e_model));
         }
+        rerr[k] = err;
+    };
+    if (n_chunks <= 256) {
+        // R candidates at a time: thread -> (candidate, chunk); then one thread per candidate adds its chunk sums in order
+        const int R = 256 / n_chunks;
+        for (int k0 = 0; k0 < n; k0 += R) {
+            const int slot = tid / n_chunks, ch = tid - slot * n_chunks;
+            const int k = k0 + slot;
+            double v = 0.0;
+            if (slot < R && k < n) {
+                const int m0 = ch * XM;
+                v = chunk_dot<T>(Tp + m0, Wp + key_pos(list[k]) + m0, min(XM, M - m0));
+            }
+            part[tid] = v;
+            __syncthreads();
+            if (tid < R && k0 + tid < n) {
+                double tot = 0.0;
+                for (int c = 0; c < n_chunks; ++c) tot += part[tid * n_chunks + c];
+                finish(k0 + tid, tot);
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int k = 0; k < n; ++k) {
+            double tot = 0.0;
+            for (int c0 = 0; c0 < n_chunks; c0 += 256) {
+                const int ch = c0 + tid;
+                const int m0 = ch * XM;
+                part[tid] = ch < n_chunks ? chunk_dot<T>(Tp + m0, Wp + key_pos(list[k]) + m0, min(XM, M - m0)) : 0.0;
+                __syncthreads();
+                if (tid == 0)
+                    for (int c = 0; c < min(256, n_chunks - c0); ++c) tot += part[c];
+                __syncthreads();
+            }
+            if (tid == 0) finish(k, tot);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256)
+void refine_kernel(RefineParams a) {
+    __shared__ unsigned long long list[RCAP], rkey[RCAP];
+    __shared__ int lpair[RCAP];
+    __shared__ float rerr[RCAP];
+    __shared__ double part[256];
+    __shared__ int cnt, ovf, violated;
+    const int tid = threadIdx.x;
+    const int s_idx = a.first_search + blockIdx.x;
+    const SearchDesc sd = a.searches[s_idx];
+    const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
+    if (tid == 0) { cnt = 0; ovf = 0; violated = 0; }
+    __syncthreads();
+    const float U = key_score(a.gkeys[s_idx]);
+    const unsigned long long* __restrict__ rows = a.cand + (size_t)(sd.first_pair - a.sub_first_pair) * FFT_ROW;
+    const int n_ent = lay.n_pairs * FFT_ROW;
+    for (int e = tid; e < n_ent; e += 256) {
+        const int slot = e % FFT_ROW;
+        if (slot == FFT_CAND + 1) continue;                                    // the pair's error bound, not a key
+        const unsigned long long key = rows[e];
+        if (key != NO_KEY && key_score(key) <= U) {
+            if (slot == FFT_CAND) {
+                ovf = 1;                                   // that pair had more candidate positions than slots
+            } else {
+                const int k = atomicAdd(&cnt, 1);
+                if (k < RCAP) { list[k] = key; lpair[k] = e / FFT_ROW; } else ovf = 1;
+            }
+        }
+    }
+    __syncthreads();
+    const int n = cnt < RCAP ? cnt : RCAP;
+    if (!ovf) {
+        if (a.r.dtype == SUSHI_HIP_F32) refine_body<float>(a, s_idx, sd, list, lpair, rows, n, part, rkey, rerr, &violated);
+        else refine_body<uint8_t>(a, s_idx, sd, list, lpair, rows, n, part, rkey, rerr, &violated);
         __syncthreads();
     }
     if (tid == 0) {
-        a.keys[s_idx] = best;
-        // diagnostics: how far the ranking stage was off at the position that won (compare with delta / 2)
-        a.gkeys[s_idx] = (unsigned long long)__float_as_uint(fabsf(best_approx - key_score(best)));
+        if (ovf || violated) {
+            // keys[s_idx] stays NO_KEY for exact_tiles_kernel; gkeys[s_idx] keeps the threshold collect_kernel needs
+            a.flags[s_idx] = violated ? 2 : 1;
+            a.flag_list[atomicAdd(a.sub_flagged, 1)] = s_idx;
+            atomicAdd(&a.counters->n_flagged, 1);
+            if (violated) atomicAdd(&a.counters->n_all_positions, 1);
+        } else {
+            unsigned long long best = NO_KEY;
+            float best_err = 0.f;
+            for (int k = 0; k < n; ++k)
+                if (rkey[k] < best) { best = rkey[k]; best_err = rerr[k]; }
+            a.keys[s_idx] = best;
+            // diagnostics: how far the ranking stage was off at the position that won
+            a.gkeys[s_idx] = (unsigned long long)__float_as_uint(best_err);
+        }
     }
+}
+
+// first launch of a sub-batch's exact stages: nothing flagged yet, no tile listed yet
+__global__ void reset_sub_kernel(int* sub_flagged, RunCounters* counters) {
+    *sub_flagged = 0;
+    counters->n_tiles = 0;
+    counters->n_cand = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -624,40 +654,11 @@ constexpr int kNumVariants = 3;
 
 namespace sushi {
 
-static MatchArgs match_args(const StreamRefs& r, const SushiHipSearch* searches_dev, int n_search, int n_tiles,
-                            unsigned long long* keys_dev) {
-    MatchArgs a;
-    a.dst_xc = r.dst_xc; a.dst_s1 = r.dst_s1; a.dst_s2 = r.dst_s2; a.dst_len = r.dst_len;
-    a.src_xc = r.src_xc; a.src_s1 = r.src_s1; a.src_s2 = r.src_s2; a.src_len = r.src_len;
-    a.centre = r.centre; a.searches = searches_dev; a.n_search = n_search; a.n_tiles = n_tiles;
-    a.keys = keys_dev;
-    return a;
-}
+int direct_variant_count() { return kNumVariants; }
 
-int launch_refine(const StreamRefs& r, const SushiHipSearch* searches_dev, int first_search, int n_sub,
-                  int sub_first_pair, const unsigned long long* cand_dev, unsigned long long* gkeys_dev,
-                  float delta, unsigned long long* keys_dev, int* flags_dev, int n_search, hipStream_t st) {
-    RefineArgs a;
-    a.r = r; a.searches = searches_dev; a.first_search = first_search; a.sub_first_pair = sub_first_pair;
-    a.cand = cand_dev; a.gkeys = gkeys_dev; a.delta = delta; a.keys = keys_dev; a.flags = flags_dev;
-    a.n_search = n_search;
-    hipLaunchKernelGGL(refine_kernel, dim3(n_sub), dim3(256), 0, st, a);
-    return launch_ok();
-}
-
-// the searches refine_kernel flagged: uint8 streams by the MFMA kernel (exact on integers), float32 streams by
-// the float64 kernel
-int launch_flagged(const StreamRefs& r, const SushiHipSearch* searches_dev, int n_search,
-                   unsigned long long* keys_dev, const int* flags_dev, hipStream_t st) {
-    if (r.dtype == SUSHI_HIP_F32 && r.dst_raw && r.src_raw) {
-        ExactArgs x;
-        x.r = r; x.searches = searches_dev; x.n_search = n_search; x.keys = keys_dev;
-        hipLaunchKernelGGL(exact_flagged_kernel, dim3(1024), dim3(256), 0, st, x, flags_dev);
-        return launch_ok();
-    }
-    const MatchArgs a = match_args(r, searches_dev, n_search, 0, keys_dev);
-    hipLaunchKernelGGL((match_flagged_kernel<4, 4>), dim3(1024), dim3(256), 0, st, a, flags_dev);
-    return launch_ok();
+int direct_variant_tile(int variant) {
+    if (variant < 0 || variant >= kNumVariants) return 0;
+    return kVariants[variant].waves * kVariants[variant].nb * 1024;
 }
 
 int launch_unpack(const unsigned long long* keys_dev, int n, int32_t* out_idx_dev, float* out_score_dev, hipStream_t st) {
@@ -665,9 +666,64 @@ int launch_unpack(const unsigned long long* keys_dev, int n, int32_t* out_idx_de
     return launch_ok();
 }
 
+int launch_direct(const StreamRefs& r, const SearchDesc* searches_dev, int n_search, int n_tiles, int variant,
+                  unsigned long long* keys_dev, int32_t* out_idx_dev, float* out_score_dev, hipStream_t st) {
+    if (n_tiles < n_search || variant < 0 || variant >= kNumVariants) return SUSHI_HIP_EINVAL;
+    if (hipMemsetAsync(keys_dev, 0xff, (size_t)n_search * sizeof(uint64_t), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+    MatchArgs a;
+    a.dst_xc = r.dst_xc; a.dst_s1 = r.dst_s1; a.dst_s2 = r.dst_s2; a.dst_len = r.dst_len;
+    a.src_xc = r.src_xc; a.src_s1 = r.src_s1; a.src_s2 = r.src_s2; a.src_len = r.src_len;
+    a.centre = r.centre; a.searches = searches_dev; a.n_search = n_search; a.n_tiles = n_tiles;
+    a.keys = keys_dev;
+    switch (variant) {
+        case 0: hipLaunchKernelGGL((match_sqdiff_f32_kernel<1, 1>), dim3(n_tiles), dim3(64), 0, st, a); break;
+        case 1: hipLaunchKernelGGL((match_sqdiff_f32_kernel<4, 1>), dim3(n_tiles), dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((match_sqdiff_f32_kernel<4, 4>), dim3(n_tiles), dim3(256), 0, st, a); break;
+    }
+    if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+    return launch_unpack(keys_dev, n_search, out_idx_dev, out_score_dev, st);
+}
+
+int launch_refine(const RefineParams& p, hipStream_t st) {
+    hipLaunchKernelGGL(reset_sub_kernel, dim3(1), dim3(1), 0, st, p.sub_flagged, p.counters);
+    if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+    hipLaunchKernelGGL(refine_kernel, dim3(p.n_sub), dim3(256), 0, st, p);
+    return launch_ok();
+}
+
+int launch_tiles(const TileParams& p, hipStream_t st) {
+    if (p.r.dtype == SUSHI_HIP_F32) hipLaunchKernelGGL(exact_tiles_kernel<float>, dim3(2048), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(exact_tiles_kernel<uint8_t>, dim3(2048), dim3(256), 0, st, p);
+    return launch_ok();
+}
+
 }  // namespace sushi
 
 using namespace sushi;
+
+namespace {
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// where the parts of a prepared stream go inside the caller's buffer
+struct StreamLayout { size_t xc, s1, s2, urel, base, base_bytes, spec, total; };
+
+StreamLayout stream_layout(int64_t n, int searchable) {
+    StreamLayout l;
+    const int64_t nb = (n + PB - 1) / PB;
+    size_t o = 0;
+    l.xc = o; o += align_up((size_t)n * sizeof(float), 256);
+    l.s1 = o; o += align_up((size_t)(n + 1) * sizeof(double), 256);
+    l.s2 = o; o += align_up((size_t)(n + 1) * sizeof(double), 256);
+    l.urel = o; o += align_up((size_t)(n + 1) * sizeof(float), 256);
+    l.base_bytes = (size_t)(2 * (nb + 1)) * sizeof(double);      // block bases of sum x^2, then (scratch) of sum x
+    l.base = o; o += align_up(l.base_bytes, 256);
+    l.spec = o; o += searchable ? align_up(sushi_hip_stream_spectra_bytes(n), 256) : 0;
+    l.total = o;
+    return l;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -679,7 +735,7 @@ const char* sushi_hip_strerror(int code) {
         case SUSHI_HIP_EINVAL: return "invalid argument";
         case SUSHI_HIP_EALIGN: return "device pointer not aligned";
         case SUSHI_HIP_ELAUNCH: return "HIP launch failed";
-        case SUSHI_HIP_ENOSPACE: return "workspace too small";
+        case SUSHI_HIP_ENOSPACE: return "buffer or workspace too small";
         case SUSHI_HIP_ENODEV: return "no gfx950 device";
         default: return "unknown sushi_hip error";
     }
@@ -697,82 +753,74 @@ int sushi_hip_device_ok(void) {
     return SUSHI_HIP_ENODEV;
 }
 
-int sushi_hip_variant_count(void) { return kNumVariants; }
-
-int sushi_hip_variant_tile_positions(int variant) {
-    if (variant < 0 || variant >= kNumVariants) return SUSHI_HIP_EINVAL;
-    return kVariants[variant].waves * kVariants[variant].nb * 1024;
-}
-
 double sushi_hip_centre(int dtype) { return dtype == SUSHI_HIP_U8 ? 128.0 : 0.5; }
 
-size_t sushi_hip_prepare_base_bytes(int64_t n) {
-    if (n < 0) return 0;
-    const int64_t nb = (n + PB - 1) / PB;
-    return (size_t)(2 * (nb + 1)) * sizeof(double);
+size_t sushi_hip_stream_bytes(int64_t n, int dtype, int searchable) {
+    if (n <= 0 || (dtype != SUSHI_HIP_U8 && dtype != SUSHI_HIP_F32)) return 0;
+    return stream_layout(n, searchable).total;
 }
 
-int sushi_hip_prepare_stream(const void* raw_dev, int dtype, int64_t n, float* xc_dev, double* s1_dev,
-                             double* s2_dev, float* urel_dev, double* base_dev, size_t base_bytes, void* hip_stream) {
-    if (!raw_dev || !xc_dev || !s1_dev || !s2_dev || !urel_dev || !base_dev || n <= 0) return SUSHI_HIP_EINVAL;
+int sushi_hip_stream_create(const void* raw_dev, int dtype, int64_t n, int searchable, void* mem_dev, size_t mem_bytes,
+                            void* hip_stream, SushiHipStream** out) {
+    if (!raw_dev || !mem_dev || !out || n <= 0) return SUSHI_HIP_EINVAL;
     if (dtype != SUSHI_HIP_U8 && dtype != SUSHI_HIP_F32) return SUSHI_HIP_EINVAL;
-    if (((uintptr_t)xc_dev & 15) || ((uintptr_t)s1_dev & 7) || ((uintptr_t)s2_dev & 7) || ((uintptr_t)base_dev & 7) ||
-        ((uintptr_t)urel_dev & 3) || (dtype == SUSHI_HIP_F32 && ((uintptr_t)raw_dev & 3)))
-        return SUSHI_HIP_EALIGN;
-    if (base_bytes < sushi_hip_prepare_base_bytes(n)) return SUSHI_HIP_ENOSPACE;
+    if (((uintptr_t)mem_dev & 255) || (dtype == SUSHI_HIP_F32 && ((uintptr_t)raw_dev & 3))) return SUSHI_HIP_EALIGN;
+    const StreamLayout l = stream_layout(n, searchable);
+    if (mem_bytes < l.total) return SUSHI_HIP_ENOSPACE;
     const int64_t nb64 = (n + PB - 1) / PB;
     if (nb64 > 0x7ffffffe) return SUSHI_HIP_EINVAL;
     const int nb = (int)nb64;
+    SushiHipStream* s = new (std::nothrow) SushiHipStream();
+    if (!s) return SUSHI_HIP_EINVAL;
+    char* m = (char*)mem_dev;
+    s->raw = raw_dev; s->dtype = dtype; s->n = n;
+    s->xc = (float*)(m + l.xc); s->s1 = (double*)(m + l.s1); s->s2 = (double*)(m + l.s2);
+    s->urel = (float*)(m + l.urel); s->base = (double*)(m + l.base); s->base_bytes = l.base_bytes;
+    s->spec = nullptr; s->spec_bytes = 0; s->blocks = nb;
     hipStream_t st = (hipStream_t)hip_stream;
-    double* bs2 = base_dev;                      // block bases of sum x^2 (what the FFT path's scoring reads)
-    double* bs1 = base_dev + (nb + 1);           // block bases of sum x
+    double* bs2 = s->base;                       // block bases of sum x^2 (what the FFT path's scoring reads)
+    double* bs1 = s->base + (nb + 1);            // block bases of sum x
     if (dtype == SUSHI_HIP_F32)
         hipLaunchKernelGGL(centre_blocksum_kernel<float>, dim3(nb), dim3(PB_THREADS), 0, st,
-                           (const float*)raw_dev, n, xc_dev, bs1, bs2);
+                           (const float*)raw_dev, n, s->xc, bs1, bs2);
     else
         hipLaunchKernelGGL(centre_blocksum_kernel<uint8_t>, dim3(nb), dim3(PB_THREADS), 0, st,
-                           (const uint8_t*)raw_dev, n, xc_dev, bs1, bs2);
-    if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-    hipLaunchKernelGGL(scan_blocksums_kernel<2>, dim3(1), dim3(1024), 0, st, base_dev, nb + 1, nb);
-    if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-    if (dtype == SUSHI_HIP_F32)
-        hipLaunchKernelGGL(final_scan_kernel<float>, dim3(nb), dim3(PB_THREADS), 0, st, (const float*)raw_dev, n,
-                           (const double*)bs1, (const double*)bs2, s1_dev, s2_dev, urel_dev);
-    else
-        hipLaunchKernelGGL(final_scan_kernel<uint8_t>, dim3(nb), dim3(PB_THREADS), 0, st, (const uint8_t*)raw_dev, n,
-                           (const double*)bs1, (const double*)bs2, s1_dev, s2_dev, urel_dev);
-    return launch_ok();
+                           (const uint8_t*)raw_dev, n, s->xc, bs1, bs2);
+    int rc = launch_ok();
+    if (rc == SUSHI_HIP_OK) {
+        hipLaunchKernelGGL(scan_blocksums_kernel<2>, dim3(1), dim3(1024), 0, st, s->base, nb + 1, nb);
+        rc = launch_ok();
+    }
+    if (rc == SUSHI_HIP_OK) {
+        if (dtype == SUSHI_HIP_F32)
+            hipLaunchKernelGGL(final_scan_kernel<float>, dim3(nb), dim3(PB_THREADS), 0, st, (const float*)raw_dev, n,
+                               (const double*)bs1, (const double*)bs2, s->s1, s->s2, s->urel);
+        else
+            hipLaunchKernelGGL(final_scan_kernel<uint8_t>, dim3(nb), dim3(PB_THREADS), 0, st, (const uint8_t*)raw_dev, n,
+                               (const double*)bs1, (const double*)bs2, s->s1, s->s2, s->urel);
+        rc = launch_ok();
+    }
+    if (rc == SUSHI_HIP_OK && searchable)
+        rc = sushi_hip_stream_add_spectra(s, m + l.spec, mem_bytes - l.spec, hip_stream);
+    if (rc != SUSHI_HIP_OK) { delete s; return rc; }
+    *out = s;
+    return SUSHI_HIP_OK;
 }
 
-int sushi_hip_match_batch(const float* dst_xc_dev, const double* dst_s1_dev, const double* dst_s2_dev, int64_t dst_len,
-                          const float* src_xc_dev, const double* src_s1_dev, const double* src_s2_dev, int64_t src_len,
-                          double centre, int method, const SushiHipSearch* searches_dev, int n_search, int n_tiles,
-                          int variant, uint64_t* keys_ws_dev, int32_t* out_idx_dev, float* out_score_dev,
-                          void* hip_stream) {
-    if (!dst_xc_dev || !dst_s1_dev || !dst_s2_dev || !src_xc_dev || !src_s1_dev || !src_s2_dev || !searches_dev ||
-        !keys_ws_dev || !out_idx_dev || !out_score_dev)
-        return SUSHI_HIP_EINVAL;
-    if (dst_len <= 0 || src_len <= 0 || n_search <= 0 || n_tiles < n_search) return SUSHI_HIP_EINVAL;
-    if (method != SUSHI_HIP_SQDIFF_NORMED) return SUSHI_HIP_EINVAL;
-    if (variant < 0 || variant >= kNumVariants) return SUSHI_HIP_EINVAL;
-    if (((uintptr_t)dst_xc_dev & 15) || ((uintptr_t)keys_ws_dev & 7) || ((uintptr_t)searches_dev & 7))
-        return SUSHI_HIP_EALIGN;
-    hipStream_t st = (hipStream_t)hip_stream;
-    if (hipMemsetAsync(keys_ws_dev, 0xff, (size_t)n_search * sizeof(uint64_t), st) != hipSuccess)
-        return SUSHI_HIP_ELAUNCH;
-    StreamRefs r;
-    r.dst_xc = dst_xc_dev; r.dst_s1 = dst_s1_dev; r.dst_s2 = dst_s2_dev; r.dst_len = dst_len;
-    r.src_xc = src_xc_dev; r.src_s1 = src_s1_dev; r.src_s2 = src_s2_dev; r.src_len = src_len;
-    r.centre = centre;
-    r.dst_raw = nullptr; r.src_raw = nullptr; r.dtype = SUSHI_HIP_F32;
-    const MatchArgs a = match_args(r, searches_dev, n_search, n_tiles, (unsigned long long*)keys_ws_dev);
-    switch (variant) {
-        case 0: hipLaunchKernelGGL((match_sqdiff_f32_kernel<1, 1>), dim3(n_tiles), dim3(64), 0, st, a); break;
-        case 1: hipLaunchKernelGGL((match_sqdiff_f32_kernel<4, 1>), dim3(n_tiles), dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((match_sqdiff_f32_kernel<4, 4>), dim3(n_tiles), dim3(256), 0, st, a); break;
+int sushi_hip_stream_view(const SushiHipStream* s, int which, const void** ptr_dev, size_t* bytes) {
+    if (!s || !ptr_dev || !bytes) return SUSHI_HIP_EINVAL;
+    switch (which) {
+        case SUSHI_HIP_VIEW_XC: *ptr_dev = s->xc; *bytes = (size_t)s->n * sizeof(float); break;
+        case SUSHI_HIP_VIEW_S1: *ptr_dev = s->s1; *bytes = (size_t)(s->n + 1) * sizeof(double); break;
+        case SUSHI_HIP_VIEW_S2: *ptr_dev = s->s2; *bytes = (size_t)(s->n + 1) * sizeof(double); break;
+        case SUSHI_HIP_VIEW_UREL: *ptr_dev = s->urel; *bytes = (size_t)(s->n + 1) * sizeof(float); break;
+        case SUSHI_HIP_VIEW_BASE: *ptr_dev = s->base; *bytes = (size_t)(s->blocks + 1) * sizeof(double); break;
+        case SUSHI_HIP_VIEW_SPECTRA: *ptr_dev = s->spec; *bytes = s->spec_bytes; break;
+        default: return SUSHI_HIP_EINVAL;
     }
-    if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-    return launch_unpack((const unsigned long long*)keys_ws_dev, n_search, out_idx_dev, out_score_dev, st);
+    return SUSHI_HIP_OK;
 }
+
+void sushi_hip_stream_destroy(SushiHipStream* s) { delete s; }
 
 }  // extern "C"

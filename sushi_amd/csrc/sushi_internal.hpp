@@ -1,4 +1,4 @@
-// sushi_amd/csrc/sushi_internal.hpp -- launchers shared between the two translation units of
+// sushi_amd/csrc/sushi_internal.hpp -- types and launchers shared between the translation units of
 // libsushi_hip.so (hidden visibility: not part of the C ABI).
 #ifndef SUSHI_INTERNAL_HPP
 #define SUSHI_INTERNAL_HPP
@@ -8,22 +8,97 @@
 
 #include "../../include/sushi_hip.h"
 
+// The opaque stream handle of the C ABI: where the parts of a prepared stream live (all inside the caller's buffer).
+struct SushiHipStream {
+    const void* raw;          // the samples as they are (uint8 / float32), caller-owned
+    int dtype;
+    int64_t n;
+    float* xc;                // [n]      sample - centre
+    double* s1;               // [n + 1]  prefix sums of the samples
+    double* s2;               // [n + 1]  prefix sums of their squares
+    float* urel;              // [n + 1]  s2 relative to the block base
+    double* base;             // [nb + 1] block bases of s2 (+ scratch behind it)
+    size_t base_bytes;
+    void* spec;               // [(nb + 1) * N] complex f32 block spectra, or null
+    size_t spec_bytes;
+    int64_t blocks;           // nb
+};
+
 namespace sushi {
+
+// One search on the device: a SushiHipRequest plus the running sums that let a workgroup find its work.
+struct SearchDesc {
+    int64_t tmpl_off;
+    int64_t win_start;
+    int32_t tmpl_len;
+    int32_t n_pos;
+    int32_t first_tile;   // direct path: tiles of the searches before this one
+    int32_t first_pair;   // FFT path: block pairs of the searches before this one
+    int32_t first_seg;    // FFT path: pattern segments of the searches before this one
+    int32_t reserved;
+};
+static_assert(sizeof(SearchDesc) == 40, "SearchDesc layout");
 
 struct StreamRefs {
     const float* dst_xc; const double* dst_s1; const double* dst_s2; int64_t dst_len;
     const float* src_xc; const double* src_s1; const double* src_s2; int64_t src_len;
     double centre;
-    const void* dst_raw; const void* src_raw; int dtype;     // the samples as they are (refine_kernel); may be null for the direct path
+    const void* dst_raw; const void* src_raw; int dtype;     // the samples as they are (exact evaluation)
 };
 
-// Exact float64 evaluation of the candidates of searches [first_search, first_search + n_sub).
-int launch_refine(const StreamRefs& r, const SushiHipSearch* searches_dev, int first_search, int n_sub,
-                  int sub_first_pair, const unsigned long long* cand_dev, unsigned long long* gkeys_dev,
-                  float delta, unsigned long long* keys_dev, int* flags_dev, int n_search, hipStream_t st);
-// Direct (MFMA) kernel over the searches the refinement flagged.
-int launch_flagged(const StreamRefs& r, const SushiHipSearch* searches_dev, int n_search,
-                          unsigned long long* keys_dev, const int* flags_dev, hipStream_t st);
+// One exact-evaluation work item: TILE consecutive positions of one search, aligned to the absolute grid.
+struct TileDesc {
+    int32_t search;       // global search index
+    int32_t p0;           // first position of the tile relative to the search's window (may be < 0 for the first tile)
+    int32_t off;          // sparse: first entry of the tile's candidate list in the candidate buffer
+    int32_t cnt;          // sparse: candidates; dense (every valid position of the tile): -1
+};
+
+// Counters of one run, in device memory (zeroed at the start of a run).
+struct RunCounters {
+    int32_t n_flagged;        // searches refine_kernel could not finish from the per-pair lists
+    int32_t n_all_positions;  // of those: every position (bound violated)
+    int32_t n_tiles;          // entries of the tile list (reset per sub-batch)
+    int32_t n_cand;           // entries of the candidate buffer (reset per sub-batch)
+    unsigned long long tiles_dense, tiles_sparse, candidates;    // totals of the run
+    uint32_t max_ratio_bits;  // float bits of SushiHipBatchDiag.max_bound_ratio
+    uint32_t pad;
+};
+
+int direct_variant_count();
+int direct_variant_tile(int variant);
+
+// direct path: one launch of the MFMA kernel + unpack
+int launch_direct(const StreamRefs& r, const SearchDesc* searches_dev, int n_search, int n_tiles, int variant,
+                  unsigned long long* keys_dev, int32_t* out_idx_dev, float* out_score_dev, hipStream_t st);
+
+// FFT path, exact stages (sushi_hip.hip):
+// refine: exact float64 evaluation of the listed candidates of searches [first_search, first_search + n_sub).
+// flags_dev[s] = 0 done / 1 needs tiles / 2 every position; flag_list_dev receives the flagged searches of this sub-batch.
+struct RefineParams {
+    StreamRefs r;
+    const SearchDesc* searches;       // all searches of the batch
+    int first_search, n_sub, sub_first_pair;
+    const unsigned long long* cand;   // [pairs of the sub-batch][FFT_ROW]
+    unsigned long long* gkeys;        // [all searches] in: min over pairs of (f32 score + bound); out: |f32 - exact| bits
+    unsigned long long* keys;         // [all searches] result keys
+    int* flags;                       // [all searches]
+    int* flag_list;                   // [n_sub] flagged searches of this sub-batch (global indices)
+    int* sub_flagged;                 // [1] how many
+    RunCounters* counters;
+    float delta;
+};
+int launch_refine(const RefineParams& p, hipStream_t st);
+
+struct TileParams {
+    StreamRefs r;
+    const SearchDesc* searches;
+    const TileDesc* tiles;
+    const int32_t* cand;              // candidate positions (relative to the search window)
+    unsigned long long* keys;
+    RunCounters* counters;            // n_tiles read on the device
+};
+int launch_tiles(const TileParams& p, hipStream_t st);
 int launch_unpack(const unsigned long long* keys_dev, int n, int32_t* out_idx_dev, float* out_score_dev, hipStream_t st);
 
 }  // namespace sushi

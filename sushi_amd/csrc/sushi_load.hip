@@ -1,13 +1,15 @@
 // sushi_amd/csrc/sushi_load.hip -- WavStream.__init__'s value pipeline on the GPU (gfx950).
 //
-// Reference wav.py:113-156 after the RIFF decode (which stays on the host): nearest-neighbour
+// Reference wav.py:64-91 (PCM decode + channel-mean downmix; only the RIFF header walk stays on the host) and
+// wav.py:113-156: nearest-neighbour
 // decimation of each one-second chunk (cv2.resize INTER_NEAREST, wav.py:125-137), edge-replicated
 // padding (:140-141), 3 x median clipping of the positive and the negative side (:145-148), scaling
 // to [0, 1] (:150-151) and optional quantisation to uint8 (:153-156).  Every float32 operation is the
 // one NumPy performs, in the same order (this translation unit is compiled with -ffp-contract=off),
 // so the resulting stream is bit-identical to the host pipeline in sushi_amd/wav.py::_build.
 //
-// All three kernels are single passes over the stream: HBM-bound, 4 B in / 4 (or 1) B out per sample.
+// All kernels are single passes over the stream: HBM-bound, 4 B in / 4 (or 1) B out per sample (decode: the
+// file's bytes in, 4 B out per frame).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -16,6 +18,25 @@
 namespace {
 
 inline int launch_ok() { return hipGetLastError() == hipSuccess ? SUSHI_HIP_OK : SUSHI_HIP_ELAUNCH; }
+
+// wav.py:64-91 DownmixedWavFile.readframes for a run of frames: every channel's sample as int16 (24-bit samples keep
+// their top two bytes, wav.py:70-74) -> float32; channels summed left to right in float32 and divided by
+// float(channels) (the reference's reduce(a + b) then `data /= float(channels_count)`).  One thread per frame;
+// a wave reads 64 consecutive frames = one contiguous run of bytes.
+template <int WIDTH>
+__global__ __launch_bounds__(256)
+void decode_downmix_kernel(const uint8_t* __restrict__ pcm, int64_t n_frames, int channels, float* __restrict__ mono) {
+    for (int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x; f < n_frames; f += (int64_t)gridDim.x * 256) {
+        const uint8_t* __restrict__ p = pcm + f * (int64_t)(channels * WIDTH) + (WIDTH - 2);
+        float acc = (float)(int16_t)((uint16_t)p[0] | ((uint16_t)p[1] << 8));
+        for (int c = 1; c < channels; ++c) {
+            const uint8_t* __restrict__ q = p + c * WIDTH;
+            acc += (float)(int16_t)((uint16_t)q[0] | ((uint16_t)q[1] << 8));
+        }
+        if (channels > 1) acc /= (float)channels;
+        mono[f] = acc;
+    }
+}
 
 struct ResampleArgs {
     const float* raw;       // downmixed frames, n_raw of them
@@ -116,6 +137,23 @@ inline unsigned grid_for(int64_t n) {
 }  // namespace
 
 extern "C" {
+
+int sushi_hip_load_decode(const void* pcm_dev, int64_t n_frames, int32_t channels, int32_t sample_width, float* mono_dev,
+                          void* hip_stream) {
+    if (!pcm_dev || !mono_dev || n_frames < 0 || channels < 1) return SUSHI_HIP_EINVAL;
+    if (sample_width != 2 && sample_width != 3) return SUSHI_HIP_EINVAL;     // wav.py:75-76: 'Unsupported sample width'
+    if ((uintptr_t)mono_dev & 3) return SUSHI_HIP_EALIGN;
+    if (n_frames == 0) return SUSHI_HIP_OK;
+    const int64_t want = (n_frames + 255) / 256;
+    const unsigned grid = (unsigned)(want < 65536 ? want : 65536);
+    if (sample_width == 2)
+        hipLaunchKernelGGL(decode_downmix_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream,
+                           (const uint8_t*)pcm_dev, n_frames, channels, mono_dev);
+    else
+        hipLaunchKernelGGL(decode_downmix_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream,
+                           (const uint8_t*)pcm_dev, n_frames, channels, mono_dev);
+    return launch_ok();
+}
 
 int sushi_hip_load_resample(const float* raw_dev, int64_t n_raw, int32_t chunk, int32_t nl_full, double scale_full,
                             int64_t n_full, int32_t rest, int32_t nl_rest, double scale_rest,

@@ -7,6 +7,7 @@ medians, clip / scale / quantise.  The result is bit-identical to ``wav.WavStrea
 normalised stream never crosses PCIe twice: the device copy is handed to ``DeviceStream`` as is.
 """
 import ctypes
+import logging
 import math
 
 import numpy as np
@@ -53,13 +54,49 @@ def _median(L, data, n, side, hist, stream):
     return float(np.float32(lo + hi) / np.float32(2.0))       # np.mean of two float32 values
 
 
+UPLOAD_CHUNK_BYTES = 32 << 20      # PCM bytes uploaded and decoded per step: bounds the host memory of a load
+
+
+def decode_file_on_device(wavfile, dev):
+    """wav.py:64-91 on the GPU: the data chunk of `wavfile` (a DownmixedWavFile positioned at its first frame) is
+    read UPLOAD_CHUNK_BYTES at a time, uploaded, decoded and downmixed by sushi_hip_load_decode into one float32
+    mono tensor.  Returns (tensor [frames], frames).  Host memory: one chunk of file bytes."""
+    L = _native.lib()
+    frame_size = wavfile.frame_size
+    if wavfile.sample_width not in (2, 3):
+        raise SushiError('Unsupported sample width: {0}'.format(wavfile.sample_width))
+    frames_total = int(wavfile.frames_count)
+    frames_per_chunk = max(1, UPLOAD_CHUNK_BYTES // frame_size)
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream(dev).cuda_stream
+        mono = torch.zeros(max(frames_total, 1), dtype=torch.float32, device=dev)
+        done = 0
+        while done < frames_total:
+            want = min(frames_per_chunk, frames_total - done)
+            blob = wavfile.read_bytes(want)
+            got = len(blob) // frame_size
+            if got == 0:
+                break                                            # file shorter than its header says
+            if len(blob) != got * frame_size:
+                logging.error("Length of audio channels didn't match. This might result in broken output")
+            staged = torch.frombuffer(bytearray(blob[:got * frame_size]), dtype=torch.uint8).to(dev)
+            _native.check(L.sushi_hip_load_decode(staged.data_ptr(), got, wavfile.channels_count, wavfile.sample_width,
+                                                  mono.data_ptr() + 4 * done, st), "sushi_hip_load_decode")
+            done += got
+            del staged                                           # stream-ordered free: the kernel above is queued first
+    return mono, done
+
+
 def build_on_device(samples, framerate, frames_count, sample_rate, sample_type, device=None, read_chunk_size=1,
                     padding_seconds=10):
-    """-> (host data ndarray (1, L) of dtype uint8/float32, device tensor of the same row, sample_count, padding_size)"""
+    """-> (host data ndarray (1, L) of dtype uint8/float32, device tensor of the same row, sample_count, padding_size)
+    `samples`: downmixed frames, a float32 host array or a float32 CUDA tensor (decode_file_on_device)."""
     if sample_type not in ('float32', 'uint8'):
         raise SushiError('Unknown sample type of WAV stream, must be uint8 or float32')
     L = _native.lib()
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    on_device = isinstance(samples, torch.Tensor)
+    dev = samples.device if on_device else \
+        (torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device))
     total_seconds = frames_count / float(framerate)
     downsample_rate = sample_rate / float(framerate)
     sample_count = math.ceil(total_seconds * sample_rate)
@@ -78,7 +115,7 @@ def build_on_device(samples, framerate, frames_count, sample_rate, sample_type, 
         raise SushiError('decimated stream does not fit its buffer')         # np.copyto would raise in the reference
     with torch.cuda.device(dev):
         st = torch.cuda.current_stream(dev).cuda_stream
-        raw = torch.from_numpy(np.ascontiguousarray(samples, dtype=np.float32)).to(dev)
+        raw = samples if on_device else torch.from_numpy(np.ascontiguousarray(samples, dtype=np.float32)).to(dev)
         data = torch.empty(total, dtype=torch.float32, device=dev)
         _native.check(L.sushi_hip_load_resample(raw.data_ptr(), n_raw, chunk, nl_full, scale_full, n_full, rest, nl_rest,
                                                 scale_rest, padding_size, total, data.data_ptr(), st),

@@ -4,10 +4,11 @@ Same constructor, attributes and methods as reference wav.py:104-188; ``find_sub
 the GPU (libsushi_hip.so) instead of ``cv2.matchTemplate`` + ``argmin`` (wav.py:185-186).
 Extensions: ``WavStream.from_samples`` (in-memory PCM), ``find_substreams`` (batched).
 
-The load pipeline (wav.py:108-162): RIFF decode and downmix on the host; decimation, padding, the
-two medians, clip / scale / quantise on the GPU when one is present (sushi_amd/load.py,
-csrc/sushi_load.hip) and otherwise in NumPy (``_build_host``, bit-identical; it is what the CPU
-tests compare with the oracle).  ``SUSHI_HIP_LOAD=host`` forces the NumPy pipeline.
+The load pipeline (wav.py:64-162): the RIFF header walk on the host; PCM decode, channel downmix, decimation,
+padding, the two medians, clip / scale / quantise on the GPU when one is present (the file is uploaded in bounded
+chunks; sushi_amd/load.py, csrc/sushi_load.hip) and otherwise in NumPy, chunk by chunk (``_build_host``,
+bit-identical; it is what the CPU tests compare with the reference-generated goldens).
+``SUSHI_HIP_LOAD=host`` forces the NumPy pipeline.
 """
 import logging
 import math
@@ -113,9 +114,21 @@ class DownmixedWavFile(object):
             return np.empty(0, np.float32)
         return self._decode(self._file.read(count * self.frame_size))
 
-    def read_all(self):
-        """All frames from the current position, downmixed."""
-        return self._decode(self._file.read(self.frames_count * self.frame_size))
+    def read_bytes(self, count):
+        """The raw bytes of the next `count` frames (fewer at the end of the file)."""
+        return self._file.read(count * self.frame_size)
+
+    def read_into(self, out, chunk_frames):
+        """Decode and downmix the frames from the current position on into the float32 array `out`,
+        `chunk_frames` at a time (bounded host memory, like the reference's one-second reads).  Returns the frames read."""
+        done = 0
+        while done < out.shape[0]:
+            data = self.readframes(min(chunk_frames, out.shape[0] - done))
+            if data.shape[0] == 0:
+                break
+            out[done:done + data.shape[0]] = data
+            done += data.shape[0]
+        return done
 
 
 _live_streams = weakref.WeakSet()
@@ -153,8 +166,19 @@ class WavStream(object):
         before_read = time()
         stream = DownmixedWavFile(path)
         try:
-            samples = stream.read_all()
-            self._build(samples, stream.framerate, stream.frames_count, sample_rate, sample_type)
+            if self._use_gpu():
+                # decode + downmix on the GPU, the file uploaded in bounded chunks (sushi_amd/load.py)
+                from .load import build_on_device, decode_file_on_device
+                mono, _ = decode_file_on_device(stream, torch_device("cuda" if device is None else device))
+                self._dev_row = None
+                self.data, self._dev_row, self.sample_count, self.padding_size = build_on_device(
+                    mono, stream.framerate, stream.frames_count, sample_rate, sample_type,
+                    read_chunk_size=self.READ_CHUNK_SIZE, padding_seconds=self.PADDING_SECONDS)
+                self.sample_rate = sample_rate
+            else:
+                samples = np.zeros(stream.frames_count, np.float32)
+                stream.read_into(samples, 10 * stream.framerate)
+                self._build_host(samples, stream.framerate, stream.frames_count, sample_rate, sample_type)
         except Exception as e:
             raise SushiError('Error while loading {0}: {1}'.format(path, e))
         finally:
@@ -192,18 +216,23 @@ class WavStream(object):
         _live_streams.add(self)
         return self
 
+    @staticmethod
+    def _use_gpu():
+        """The load pipeline runs on the GPU when there is one (SUSHI_HIP_LOAD=host forces NumPy: it is what the CPU
+        tests compare with the reference-generated goldens, and what bench.py uses before it forks)."""
+        if os.environ.get("SUSHI_HIP_LOAD", "auto") == "host":
+            return False
+        try:
+            import torch
+            return torch.cuda.is_available()
+        except ImportError:
+            return False
+
     def _build(self, samples, framerate, frames_count, sample_rate, sample_type):
         """wav.py:113-156: on the GPU if there is one (the normalised row then stays in HBM for the
         matching), else in NumPy."""
         self._dev_row = None
-        use_gpu = os.environ.get("SUSHI_HIP_LOAD", "auto") != "host"
-        if use_gpu:
-            try:
-                import torch
-                use_gpu = torch.cuda.is_available()
-            except ImportError:
-                use_gpu = False
-        if not use_gpu:
+        if not self._use_gpu():
             return self._build_host(samples, framerate, frames_count, sample_rate, sample_type)
         from .load import build_on_device
         self.data, self._dev_row, self.sample_count, self.padding_size = build_on_device(

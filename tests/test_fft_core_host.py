@@ -19,8 +19,8 @@ def _build_and_run(tmp_path, name):
 def test_workgroup_fft_on_host(tmp_path):
     r = _build_and_run(tmp_path, "host_fft_check")
     assert r.returncode == 0, r.stdout + r.stderr
-    errs = [float(x) for x in r.stdout.split()]          # forward / inverse: 512 x 16, 256 x 32, 512 x 16 split exchange
-    assert len(errs) == 6 and max(errs) < 8e-7           # relative L2 error of an 8192-point f32 FFT
+    errs = [float(x) for x in r.stdout.split()]          # forward / inverse: 8192 points (512 x 16), 16384 points (1024 x 16)
+    assert len(errs) == 4 and max(errs) < 8e-7           # relative L2 error of an f32 FFT of these lengths
 
 
 def test_mac_ring_on_host(tmp_path):
@@ -34,36 +34,39 @@ def test_twiddle_table_is_correctly_rounded():
     path = build.write_twiddles()
     vals = np.array([float(t.strip().rstrip("f")) for t in open(path).read().replace("\n", " ").split(",") if t.strip()],
                     dtype=np.float64)
-    assert vals.shape[0] == 2 * 8192
-    k = np.arange(8192)
-    assert (vals[0::2].astype(np.float32) == np.cos(2 * np.pi * k / 8192).astype(np.float32)).all()
-    assert (vals[1::2].astype(np.float32) == (-np.sin(2 * np.pi * k / 8192)).astype(np.float32)).all()
+    assert vals.shape[0] == 2 * 16384
+    k = np.arange(16384)
+    assert (vals[0::2].astype(np.float32) == np.cos(2 * np.pi * k / 16384).astype(np.float32)).all()
+    assert (vals[1::2].astype(np.float32) == (-np.sin(2 * np.pi * k / 16384)).astype(np.float32)).all()
 
 
-def test_overlap_save_formulation_matches_definition(oracle):
-    """NumPy model of the FFT path's block arithmetic (pairing of blocks, segmenting of templates,
-    which output goes where) against the definition; the HIP kernels implement exactly this layout
-    (sushi_hip_fft_layout / csrc/sushi_common.hpp fft_layout)."""
-    from sushi_amd import _native
+@pytest.mark.parametrize("ratio", [2, 4])
+def test_overlap_save_formulation_matches_definition(oracle, ratio):
+    """NumPy model of the FFT path's block arithmetic (packing of two real blocks H = N - B apart into one complex
+    block, segmenting of patterns, the absolute pair grid, which output goes where) against the definition, for
+    N = 2 B (one valid block per half) and N = 4 B (three: the product's geometry).  The HIP kernels implement exactly
+    this layout (csrc/sushi_common.hpp fft_layout)."""
     B = 256
-    N = 2 * B
+    N = ratio * B
+    H = N - B
+    STEP = 2 * H // B
     rng = np.random.default_rng(1)
     n_dst = 20000
     xc = ((rng.standard_normal(n_dst) * 0.2 + 0.5).clip(0, 1).astype(np.float32) - np.float32(0.5))
     tc = ((rng.standard_normal(5000) * 0.2 + 0.5).clip(0, 1).astype(np.float32) - np.float32(0.5))
     J = -(-n_dst // B)
-    pad = np.zeros((J + 3) * B + N, np.float32)
+    pad = np.zeros((J + 3) * B + 2 * N + H, np.float32)
     pad[:n_dst] = xc
-    Z = np.stack([np.fft.fft(pad[j * B:j * B + N].astype(np.complex128) + 1j * pad[(j + 1) * B:(j + 1) * B + N])
+    Z = np.stack([np.fft.fft(pad[j * B:j * B + N].astype(np.complex128) + 1j * pad[j * B + H:j * B + H + N])
                   for j in range(J)])
 
     def getz(j):
         return Z[j] if j < J else np.zeros(N, np.complex128)
 
     for (to, M, w, P) in [(100, 1300, 3000, 9000), (0, 255, 0, 100), (7, 256, 255, 513), (50, 3000, 1234, 13000),
-                          (0, 700, n_dst - 1500, 801)]:
-        k0, kl = w // B, (w + P - 1) // B
-        npairs, S = (kl - k0 + 2) // 2, -(-M // B)
+                          (0, 700, n_dst - 1500, 801), (3, 1, 1535, 2)]:
+        pair0, pair_last = (w // B) // STEP, ((w + P - 1) // B) // STEP
+        S = -(-M // B)
         tt = []
         for s in range(S):
             seg = np.zeros(N)
@@ -71,13 +74,13 @@ def test_overlap_save_formulation_matches_definition(oracle):
             seg[:ln] = tc[to + s * B:to + s * B + ln]
             tt.append(np.conj(np.fft.fft(seg)) / N)
         corr = np.full(P, np.nan)
-        for i in range(npairs):
-            Y = sum(tt[s] * getz(k0 + 2 * i + s) for s in range(S))
+        for I in range(pair0, pair_last + 1):
+            Y = sum(tt[s] * getz(STEP * I + s) for s in range(S))
             y = np.fft.ifft(Y) * N
             for half, vals in ((0, y.real), (1, y.imag)):
-                p = (k0 + 2 * i + half) * B + np.arange(B) - w
+                p = STEP * I * B + half * H + np.arange(H) - w
                 ok = (p >= 0) & (p < P)
-                corr[p[ok]] = vals[:B][ok]
+                corr[p[ok]] = vals[:H][ok]
         ref = np.array([np.dot(tc[to:to + M].astype(np.float64), pad[w + p:w + p + M].astype(np.float64))
                         for p in range(P)])
         assert not np.isnan(corr).any()
