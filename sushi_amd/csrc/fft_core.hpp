@@ -122,30 +122,19 @@ SUSHI_HD Twiddles load_twiddles(int tid, const cpx* __restrict__ tw) {
 
 // One pass, register side: twiddle (unless NS == 1) and butterfly the 16 points of this thread.
 // v[b*R + t] holds input t of the thread's butterfly b; w1 is the base twiddle (shared by all of them).
-// The powers w^t are built from the squarings w, w^2, w^4, w^8 only (each w^t = product of the
-// squarings its binary digits select, at most three multiplications deep): four live twiddle registers
-// instead of R, which is what lets the wide passes coexist with everything else in a 64-register budget.
+// The powers w^t are built one multiplication at a time (w^t = w^(t-1) * w): two live twiddle registers instead of R,
+// R - 2 complex multiplications instead of the ~2R of a squaring scheme, and the same rounding error at t = R - 1
+// (t errors of the base twiddle plus t - 1 product roundings either way).
 template <int R, int NS, int DIR>
 SUSHI_HD void pass_compute(cpx* v, const cpx w1) {
     constexpr int NB = PER / R;
     if (NS > 1) {
-        cpx sq[4];
-        sq[0] = w1;
-#pragma unroll
-        for (int q = 1; q < 4; ++q) sq[q] = cmul(sq[q - 1], sq[q - 1]);
+        cpx wt = w1;
 #pragma unroll
         for (int t = 1; t < R; ++t) {
-            cpx wt = cpx{1.f, 0.f};
-            bool first = true;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (t & (1 << q)) {
-                    wt = first ? sq[q] : cmul(wt, sq[q]);
-                    first = false;
-                }
-            }
 #pragma unroll
             for (int b = 0; b < NB; ++b) v[b * R + t] = cmul(v[b * R + t], wt);
+            if (t + 1 < R) wt = cmul(wt, w1);
         }
     }
 #pragma unroll

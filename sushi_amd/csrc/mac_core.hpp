@@ -53,7 +53,11 @@ SUSHI_MAC_HD void group_range(long long pair_lo, long long pair_hi, long long* j
 }
 
 // One group: rows jb .. jb + SMAX - 1 (jb a multiple of SMAX).  get_z(u) -> Z_{jb + u} (+ the chunk's shift).
-// store(I - pair_lo, value) is called for every pair of [pair_lo, pair_hi) that completes in this group.
+// store(I - pair_lo, valid, value) is called for EVERY pair that completes in this group -- SMAX / STEP calls per group,
+// unconditionally, `valid` telling whether the pair belongs to [pair_lo, pair_hi): the device caller turns an invalid one
+// into a store to a dummy line instead of branching around it, so that the number of memory operations per group is
+// a compile-time constant (with a conditional store in the loop the compiler cannot count what is in flight and drains
+// every outstanding load at every group).
 template <int SMAX, int STEP, class GetZ, class Store>
 SUSHI_MAC_HD void mac_group(const long long jb, const long long pair_lo, const long long pair_hi,
                             const c2 (&tt)[SMAX], c2 (&acc)[SMAX / STEP], GetZ& get_z, Store& store) {
@@ -73,7 +77,7 @@ SUSHI_MAC_HD void mac_group(const long long jb, const long long pair_lo, const l
         if (u % STEP == STEP - 1) {                                     // the pair whose last segment this was
             const long long I = ib + (u - (SMAX - 1)) / STEP;          // exact division (possibly negative)
             const int slot = (((u - (SMAX - 1)) + SMAX) / STEP) % RING;
-            if (I >= pair_lo && I < pair_hi) store((int)(I - pair_lo), acc[slot]);
+            store((int)(I - pair_lo), I >= pair_lo && I < pair_hi, acc[slot]);
         }
     }
 }

@@ -31,7 +31,8 @@ static double run(int n_seg, int pair_lo, int npairs, int nz_avail) {
         for (auto& a : acc) a = c2{7e7f, 7e7f, 7e7f, 7e7f};                   // garbage: every pair must start with mul2
         for (long long jb = jb0; jb <= jb1; jb += SMAX) {
             auto get_z = [&](int u) { return lz(jb + u + (long long)c * SMAX); };
-            auto store = [&](int i, const c2 v) {
+            auto store = [&](int i, bool valid, const c2 v) {
+                if (!valid) return;
                 if (c == 0) Y[i] = v;
                 else { Y[i].ax += v.ax; Y[i].ay += v.ay; Y[i].bx += v.bx; Y[i].by += v.by; }
             };

@@ -1,10 +1,12 @@
-# A/B of library variants built under gpurun_scratch/ (dev): bench each, first against the parity sample
+# bench.py over variant libraries (VARIANTS="abl1 abl2 ..."; each sushi_amd/lib/libsushi_hip_<v>.so), dev A/B
 set -x
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for lib in $LIBS; do
-for rep in 1 2; do
-SUSHI_HIP_LIB=$lib timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/var.json 2>gpurun_out/var.err || tail -3 gpurun_out/var.err
-python -c "import json,sys;d=json.load(open('gpurun_out/var.json'));print('VAR', '$lib', round(d['value']), d['parity']['max_shift_err_samples_vs_planted'], d['roofline']['stage_ms'])" | tee -a gpurun_out/variants.txt
+export SUSHI_BENCH_CACHE=/tmp/sushi_bench_cache
+show() { python -c "
+import json,sys;d=json.load(open(sys.argv[1]));r=d['roofline'];print(sys.argv[2],round(d['value']),round(d['ms_per_step'],2),{k:round(v,2) for k,v in r['stage_ms'].items()})" $1 $2; }
+python bench.py --steps 10 --warmup 2 --no-cpu-baseline ${BENCH_ARGS:-} > gpurun_out/var_base.json 2>gpurun_out/var.err; show gpurun_out/var_base.json base
+for v in ${VARIANTS:-}; do
+  SUSHI_HIP_LIB=$GRAFT_REPO_ROOT/sushi_amd/lib/libsushi_hip_$v.so python bench.py --steps 10 --warmup 2 --no-cpu-baseline --skip-verify ${BENCH_ARGS:-} > gpurun_out/var_$v.json 2>>gpurun_out/var.err; show gpurun_out/var_$v.json $v
 done
-done
+tail -3 gpurun_out/var.err
