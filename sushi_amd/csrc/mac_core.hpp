@@ -64,9 +64,16 @@ SUSHI_MAC_HD void mac_group(const long long jb, const long long pair_lo, const l
     static_assert(SMAX % STEP == 0 && SMAX >= STEP, "SMAX must be a multiple of STEP");
     constexpr int RING = SMAX / STEP;
     const long long ib = jb / STEP;                                    // jb is a multiple of SMAX, hence of STEP
+    // rows are requested two steps before their use (get_z is an LDS read on the device: its latency then hides
+    // behind the multiply-accumulates of two rows instead of being waited for at every row)
+    constexpr int ZP = 3;
+    c2 zq[ZP];
+#pragma unroll
+    for (int u = 0; u < ZP - 1 && u < SMAX; ++u) zq[u] = get_z(u);
 #pragma unroll
     for (int u = 0; u < SMAX; ++u) {
-        const c2 z = get_z(u);
+        const c2 z = zq[u % ZP];
+        if (u + ZP - 1 < SMAX) zq[(u + ZP - 1) % ZP] = get_z(u + ZP - 1);
         // Z_{jb+u} belongs to the pair starting at block jb + u - s: same residue mod STEP as u
 #pragma unroll
         for (int s = (u % STEP); s < SMAX; s += STEP) {
