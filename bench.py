@@ -134,7 +134,6 @@ def main():
     ap.add_argument("--ws-mb", type=int, default=None, help="FFT path scratch per batch (MiB); default: what one "
                                                             "sub-batch for the whole shard needs, at most 160 GiB")
     ap.add_argument("--delta", type=float, default=None)
-    ap.add_argument("--skip-verify", action="store_true", help="dev: time a variant library whose results are wrong on purpose")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     custom = False
@@ -253,7 +252,7 @@ def main():
     ev_starts = np.array([s for s, _ in events])
     v_times = np.array(start_times) + v_idx.cpu().numpy().astype(np.float64) / float(rate)
     v_err = np.abs((v_times - ev_starts) - args.offset) * rate
-    if float(v_err[~hard_mask].max()) > 1.0 and not args.skip_verify:
+    if float(v_err[~hard_mask].max()) > 1.0:
         raise SystemExit("verification pass: planted offset not recovered (max error %.3f samples)"
                          % float(v_err[~hard_mask].max()))
     for _ in range(args.warmup):

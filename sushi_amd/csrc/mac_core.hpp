@@ -8,9 +8,9 @@
 // spectra.  Z is consumed in groups of SMAX consecutive absolute blocks jb .. jb + SMAX - 1, jb a multiple of
 // SMAX: Z_j meets the segments of its own residue (s = j - STEP*I) and feeds a ring of SMAX/STEP live outputs;
 // pair I is complete when Z_{STEP*I + SMAX - 1} has been consumed (segments n_seg .. SMAX-1 are zero).
-// Because the grouping is absolute, the searches of one workgroup (one per wave, mac_kernel) walk the same
-// groups in lockstep and share every Z row through LDS: a row is fetched from L2 once per workgroup instead
-// of once per search.
+// Because the grouping is absolute, the searches that share a wave (one per group of eight lanes, mac_kernel)
+// walk the same groups together and read every Z row at the same address: a row is fetched from L2 once per
+// wave instead of once per search.
 // Patterns with more than SMAX segments are handled SMAX segments at a time (Y accumulating): chunk c pairs
 // segments c*SMAX + s with blocks STEP*I + c*SMAX + s, i.e. the same walk over rows shifted by c*SMAX.
 #ifndef SUSHI_MAC_CORE_HPP

@@ -15,14 +15,11 @@ namespace sushi {
 // block of N samples yields FFT_H = N - FFT_SEG valid positions; two real blocks FFT_H apart are packed into one
 // complex block (a "pair": 2 * FFT_H positions per transform).  Spectra are kept at every multiple of FFT_SEG
 // ("block" j = samples from j * FFT_SEG on); consecutive pairs of a search are FFT_STEP blocks apart.
-#ifndef SUSHI_FFT_LOGN
-#define SUSHI_FFT_LOGN 14
-#endif
-constexpr int FFT_LOGN = SUSHI_FFT_LOGN;
+constexpr int FFT_LOGN = 14;
 constexpr int FFT_N = 1 << FFT_LOGN;
 constexpr int FFT_SEG = 4096;
 constexpr int FFT_HOP = FFT_SEG;                   // also the block size of the relative window-energy prefix (urel / base)
-constexpr int FFT_VB = FFT_N / FFT_SEG - 1;        // valid blocks per half of a pair: 1 (N = 8192) or 3 (N = 16384)
+constexpr int FFT_VB = FFT_N / FFT_SEG - 1;        // valid blocks per half of a pair: 3
 constexpr int FFT_H = FFT_VB * FFT_SEG;            // result positions per half
 constexpr int FFT_STEP = 2 * FFT_VB;               // blocks between consecutive pairs
 constexpr int FFT_CAND = 8;                        // candidate slots per block pair (+ overflow marker + error bound)
@@ -160,8 +157,8 @@ __host__ __device__ inline FftLayout fft_layout(int64_t win_start, int n_pos, in
 
 // segment-count class of a search: the smallest SMAX (a multiple of FFT_STEP) that holds the whole pattern;
 // longer patterns use the largest class and several chunks
-constexpr int MAC_CLASSES = FFT_STEP == 2 ? 4 : 3;
-__host__ __device__ inline int mac_class_smax(int c) { return FFT_STEP == 2 ? 4 * (c + 1) : 6 * (c + 1); }
+constexpr int MAC_CLASSES = 3;
+__host__ __device__ inline int mac_class_smax(int c) { return FFT_STEP * (c + 1); }
 __host__ __device__ inline int mac_class(int n_seg) {
     for (int c = 0; c < MAC_CLASSES - 1; ++c)
         if (n_seg <= mac_class_smax(c)) return c;

@@ -243,7 +243,15 @@ static_assert(XT == 1024 && XM % 4 == 0, "exact_tiles_kernel: 256 threads x 4 co
 template <typename T>
 __device__ __forceinline__ double chunk_dot(const T* __restrict__ t, const T* __restrict__ w, int mc) {
     double acc = 0.0;
-    for (int m = 0; m < mc; ++m) acc = __builtin_fma((double)t[m], (double)w[m], acc);
+    int m = 0;
+    for (; m + 8 <= mc; m += 8) {                       // eight independent loads in flight, then the additions in order
+        T a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a[j] = t[m + j]; b[j] = w[m + j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_fma((double)a[j], (double)b[j], acc);
+    }
+    for (; m < mc; ++m) acc = __builtin_fma((double)t[m], (double)w[m], acc);
     return acc;
 }
 

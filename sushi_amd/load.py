@@ -70,16 +70,18 @@ def decode_file_on_device(wavfile, dev):
     with torch.cuda.device(dev):
         st = torch.cuda.current_stream(dev).cuda_stream
         mono = torch.zeros(max(frames_total, 1), dtype=torch.float32, device=dev)
+        stage = bytearray(min(frames_per_chunk, max(frames_total, 1)) * frame_size)     # the one host buffer of the load
         done = 0
         while done < frames_total:
             want = min(frames_per_chunk, frames_total - done)
-            blob = wavfile.read_bytes(want)
-            got = len(blob) // frame_size
+            nbytes = wavfile.read_bytes_into(memoryview(stage)[:want * frame_size])
+            got = nbytes // frame_size
             if got == 0:
                 break                                            # file shorter than its header says
-            if len(blob) != got * frame_size:
+            if nbytes != got * frame_size:
                 logging.error("Length of audio channels didn't match. This might result in broken output")
-            staged = torch.frombuffer(bytearray(blob[:got * frame_size]), dtype=torch.uint8).to(dev)
+            # (a pageable-memory upload returns when the bytes have left `stage`: it can be refilled right away)
+            staged = torch.frombuffer(stage, dtype=torch.uint8, count=got * frame_size).to(dev)
             _native.check(L.sushi_hip_load_decode(staged.data_ptr(), got, wavfile.channels_count, wavfile.sample_width,
                                                   mono.data_ptr() + 4 * done, st), "sushi_hip_load_decode")
             done += got

@@ -114,9 +114,9 @@ class DownmixedWavFile(object):
             return np.empty(0, np.float32)
         return self._decode(self._file.read(count * self.frame_size))
 
-    def read_bytes(self, count):
-        """The raw bytes of the next `count` frames (fewer at the end of the file)."""
-        return self._file.read(count * self.frame_size)
+    def read_bytes_into(self, view):
+        """Fill `view` (a writable bytes-like object) with the next raw frame bytes; returns how many were read."""
+        return self._file.readinto(view)
 
     def read_into(self, out, chunk_frames):
         """Decode and downmix the frames from the current position on into the float32 array `out`,

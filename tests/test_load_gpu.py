@@ -57,3 +57,58 @@ def test_host_pipeline_can_be_forced(monkeypatch):
     monkeypatch.setenv("SUSHI_HIP_LOAD", "host")
     w = WavStream.from_samples(synth.make_dst_pcm(3, 12000, seed=1), 12000)
     assert w._dev_row is None
+
+
+def test_wav_load_budget_of_the_reference_regression_test(tmp_path):
+    """regression-tests.py:140-158 (run_wav_test) with the thresholds of tests.example.json:24-27: loading a WAV into a
+    WavStream may cost at most 0.7 s of CPU time and 120 MB of resident memory -- measured the reference's way
+    (resource.getrusage before / after the constructor), on a 24-minute 48 kHz stereo 16-bit file (276 MB), sample_type
+    uint8 at 12 kHz.  The file goes to the GPU in 32 MB pieces and is decoded, downmixed, decimated and normalised there."""
+    import resource
+    import struct
+    from sushi_amd.wav import WavStream
+    rate, channels, seconds = 48000, 2, 24 * 60
+    path = os.path.join(str(tmp_path), "long.wav")
+    rng = np.random.default_rng(3)
+    second = (rng.standard_normal((rate, channels)) * 3000).astype('<i2').tobytes()
+    n_bytes = len(second) * seconds
+    with open(path, "wb") as f:
+        f.write(b'RIFF' + struct.pack('<L', 36 + n_bytes) + b'WAVE')
+        f.write(b'fmt ' + struct.pack('<LHHLLHH', 16, 1, channels, rate, rate * channels * 2, channels * 2, 16))
+        f.write(b'data' + struct.pack('<L', n_bytes))
+        for _ in range(seconds):
+            f.write(second)
+    WavStream(path, sample_rate=12000, sample_type='uint8')           # warm: HIP context, kernels, allocator pools
+    before = resource.getrusage(resource.RUSAGE_SELF)
+    s = WavStream(path, sample_rate=12000, sample_type='uint8')
+    after = resource.getrusage(resource.RUSAGE_SELF)
+    cpu = (after.ru_utime + after.ru_stime) - (before.ru_utime + before.ru_stime)
+    rss_mb = (after.ru_maxrss - before.ru_maxrss) / 1024.0
+    print("WavStream load: %.3f s CPU, +%.1f MB max RSS" % (cpu, rss_mb))
+    assert s.data.shape == (1, 20 * rate + seconds * 12000) and s.data.dtype == np.uint8
+    assert s._dev_row is not None
+    assert cpu <= 0.7, cpu
+    assert rss_mb <= 120.0, rss_mb
+
+
+def test_device_decode_matches_host_decode():
+    """sushi_hip_load_decode (wav.py:64-91 on the GPU) against DownmixedWavFile._decode, bit for bit: 16- and 24-bit
+    samples, 1 to 6 channels, frame counts that are not multiples of anything."""
+    import torch
+    from sushi_amd import _native
+    from sushi_amd.wav import DownmixedWavFile
+    L = _native.lib()
+    rng = np.random.default_rng(9)
+    for width in (2, 3):
+        for channels in (1, 2, 3, 6):
+            n = 10007
+            blob = rng.integers(0, 256, n * channels * width, dtype=np.uint8).tobytes()
+            host = DownmixedWavFile.__new__(DownmixedWavFile)
+            host.sample_width, host.channels_count, host._file = width, channels, None
+            want = host._decode(blob)
+            pcm = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+            out = torch.empty(n, dtype=torch.float32, device="cuda")
+            rc = L.sushi_hip_load_decode(pcm.data_ptr(), n, channels, width, out.data_ptr(), None)
+            assert rc == 0
+            got = out.cpu().numpy()
+            assert (got.view(np.uint32) == want.view(np.uint32)).all(), (width, channels)
