@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
-"""profiles/<round>/fft_pmc_summary.csv -> profiles/pmc_traffic.json, the per-launch HBM bytes bench.py
-reports as roofline.traffic (rocprofv3 PMC passes cannot run inside the timed bench process).
-FETCH_SIZE / WRITE_SIZE are in KiB per dispatch.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE
-reads exactly half of the bytes of a wide (16 B/lane) coalesced stream -> doubled for mac_kernel and
-ifft_kernel, whose bulk reads (block spectra; Y) are dwordx4 loads (ifft: 2 x 6.14 GB = 12.3 GB against the
-11.6 GB of Y it must read plus 64 KiB of window energies per pair, mostly L2 hits)."""
+"""profiles/<round>/<summary>.csv -> profiles/pmc_traffic.json, the per-launch HBM bytes bench.py reports as
+roofline.traffic (rocprofv3 PMC passes cannot run inside the timed bench process).
+usage: make_pmc_traffic.py summary.csv pmc_traffic.json <workload key> <source commit>
+FETCH_SIZE / WRITE_SIZE are in KiB per dispatch.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reads exactly
+half of the bytes of a wide (16 B/lane) coalesced stream -> doubled for mac_kernel and ifft_kernel, whose bulk reads
+(block spectra rows; Y) are dwordx4 loads.  The entry records the digest of the kernel sources it was measured on
+(bench.kernel_source_digest): bench.py reports the traffic only while the digest still matches."""
 import csv
 import json
+import os
 import sys
 
-summary, out, workload = sys.argv[1], sys.argv[2], sys.argv[3]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+summary, out, workload, commit = sys.argv[1:5]
 rows = {r['kernel'].split('<')[0]: r for r in csv.DictReader(open(summary))}       # template arguments dropped
 res = {}
-for k, fetch_scale in (('ifft_kernel', 2.0), ('mac_kernel', 2.0), ('tspec_kernel', 1.0), ('refine_kernel', 1.0)):
+for k, fetch_scale in (('ifft_kernel', 2.0), ('mac_kernel', 2.0), ('tspec_kernel', 1.0), ('refine_kernel', 1.0),
+                       ('collect_kernel', 2.0), ('exact_tiles_kernel', 1.0)):
     if k in rows and rows[k].get('FETCH_SIZE') and rows[k].get('WRITE_SIZE'):
         res[k] = {"fetch_bytes": float(rows[k]['FETCH_SIZE']) * 1024 * fetch_scale,
                   "write_bytes": float(rows[k]['WRITE_SIZE']) * 1024,
@@ -21,6 +27,7 @@ try:
     allw = json.load(open(out))
 except Exception:
     allw = {}
-allw[workload] = {"source": summary, "kernels": res}
+allw[workload] = {"source": summary, "source_commit": commit, "kernel_source_digest": bench.kernel_source_digest(),
+                  "kernels": res}
 json.dump(allw, open(out, 'w'), indent=1, sort_keys=True)
 print(json.dumps(allw[workload], indent=1))
