@@ -15,7 +15,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 summary, out, workload, commit = sys.argv[1:5]
-rows = {r['kernel'].split('<')[0]: r for r in csv.DictReader(open(summary))}       # template arguments dropped
+rows = {}                                                  # template instances of one kernel (mac_kernel<0..5>: one dispatch
+for r in csv.DictReader(open(summary)):                    # each per step) add up to that kernel's bytes per step
+    k = r['kernel'].split('<')[0]
+    if k in rows:
+        for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+            if r.get(c) and rows[k].get(c):
+                rows[k][c] = str(float(rows[k][c]) + float(r[c]))
+        rows[k]['dispatches'] = str(max(int(rows[k]['dispatches']), int(r['dispatches'])))
+    else:
+        rows[k] = dict(r)
 res = {}
 for k, fetch_scale in (('ifft_kernel', 2.0), ('mac_kernel', 2.0), ('tspec_kernel', 1.0), ('refine_kernel', 1.0),
                        ('collect_kernel', 2.0), ('exact_tiles_kernel', 1.0)):
