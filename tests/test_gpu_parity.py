@@ -494,14 +494,14 @@ def _planted_config(seconds, rate, window, n_events, off_s, seed, n_oracle, orac
 
 def test_config3_sizes_two_hour_streams_120s_window(oracle):
     """BASELINE configs[2] sizes: 2-h 12 kHz streams, +-120 s (P = 2,880,001); one rank's worth of events
-    is 375 -- 48 here."""
-    _planted_config(7200, 12000, 120, 48, 11.5, seed=31, n_oracle=2, oracle=oracle)
+    is 375 -- 48 here, every one of them compared with the oracle (0.4 s of CPU each)."""
+    _planted_config(7200, 12000, 120, 48, 11.5, seed=31, n_oracle=48, oracle=oracle)
 
 
 def test_config5_sizes_24khz_four_hour_streams(oracle):
     """BASELINE configs[4] sizes: 4-h 24 kHz streams (346 M samples, 5.5 GB of block spectra), +-120 s
     (P = 5,760,001), templates up to 5 s = 120,000 samples = 30 segments (two multiply-accumulate chunks)."""
-    _planted_config(14400, 24000, 120, 8, -17.25 + 40.0, seed=41, n_oracle=1, oracle=oracle, min_len=3.0, max_len=5.0)
+    _planted_config(14400, 24000, 120, 8, -17.25 + 40.0, seed=41, n_oracle=8, oracle=oracle, min_len=3.0, max_len=5.0)
 
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.float32])

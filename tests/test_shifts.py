@@ -174,18 +174,18 @@ def test_lookahead_grows_while_the_shift_holds(oracle):
     assert proxy.lookahead > 4
 
 
-def _pipeline(src, dst, events, chapters, window=10, max_window=30, rewind=5):
+def _pipeline(src, dst, events, chapters, window=10, max_window=30, rewind=5, shifts=calculate_shifts_batched):
     """sushi.run's audio path (sushi.py:624-626, 664-670, 682-704): search groups, shifts, grouping."""
     from sushi_amd import grouping
     groups = grouping.prepare_search_groups(events, src.duration_seconds, chapters, 1001.0 / 24000.0 * 10, 2)
-    calculate_shifts_batched(src, dst, groups, window, max_window, rewind)
+    shifts(src, dst, groups, window, max_window, rewind)
     return grouping.group_shifts(events, chapters, smooth_radius=3)
 
 
-def _config4_events(rng, seconds, n):
+def _config4_events(rng, seconds, n, first=8.0, tail=12.0):
     """A script with what prepare_search_groups has to deal with: dialogue, a comment, a zero-length line,
     an exact duplicate and a run of short typesetting lines."""
-    starts = np.sort(rng.uniform(8.0, seconds - 12.0, n))
+    starts = np.sort(rng.uniform(first, seconds - tail, n))
     events = []
     for s in starts:
         if events and s < events[-1].end + 0.05:
@@ -240,4 +240,31 @@ def test_config4_pipeline_on_gpu_matches_oracle_run(oracle, sample_type):
         else:
             assert abs(a.shift - b.shift) <= 1e-6                       # score-weighted averages of identical positions
         if true_off(a.start) == true_off(a.end):                       # a line across a chapter mark follows its END (sushi.py:137)
+            assert abs(a.shift - true_off(a.start)) <= 1.5 / 12000, (a.start, a.shift)
+
+
+@pytest.mark.gpu
+def test_config4_stated_sizes_on_gpu_matches_oracle_run(oracle):
+    """BASELINE configs[3] at the sizes SURVEY 8(d) states: five chapters with offsets -30, -12, +3, +17, +30 s,
+    12 kHz streams, small window 10 s, maximum window 60 s (so that every jump between chapters is reachable),
+    through prepare_search_groups -> calculate_shifts (batched, HIP path) -> the --grouping block; against the same
+    pipeline with the oracle doing the matching and against the planted offsets."""
+    OracleBackedStream.oracle = oracle
+    offsets = (-30.0, -12.0, 3.0, 17.0, 30.0)
+    chapter_s = 300.0
+    pieces = [(k * chapter_s, off) for k, off in enumerate(offsets)]
+    seconds = int(chapter_s * len(offsets))
+    src, dst, _, true_off = _scenario(12000, seconds, pieces, 10, "float32", WavStream, seed=43)
+    osrc = OracleBackedStream.__new__(OracleBackedStream); osrc.__dict__.update(src.__dict__)
+    odst = OracleBackedStream.__new__(OracleBackedStream); odst.__dict__.update(dst.__dict__)
+    ev_gpu = _config4_events(np.random.default_rng(10), seconds, 140, first=36.0, tail=48.0)
+    ev_cpu = [ScriptEvent(e.start, e.end, is_comment=e.is_comment) for e in ev_gpu]
+    chapters = [t for t, _ in pieces]
+    g_gpu = _pipeline(src, dst, ev_gpu, chapters, window=10, max_window=60)
+    g_cpu = _pipeline(osrc, odst, ev_cpu, chapters, window=10, max_window=60, shifts=calculate_shifts)   # sequential: no speculated searches to pay for
+    assert [len(g) for g in g_gpu] == [len(g) for g in g_cpu] and len(g_gpu) == len(pieces)
+    for a, b in zip(ev_gpu, ev_cpu):
+        assert a.linked == b.linked
+        assert abs(a.shift - b.shift) <= 1e-6                           # score-weighted averages of identical positions
+        if true_off(a.start) == true_off(a.end):
             assert abs(a.shift - true_off(a.start)) <= 1.5 / 12000, (a.start, a.shift)
