@@ -252,9 +252,22 @@ def main():
     ev_starts = np.array([s for s, _ in events])
     v_times = np.array(start_times) + v_idx.cpu().numpy().astype(np.float64) / float(rate)
     v_err = np.abs((v_times - ev_starts) - args.offset) * rate
-    if float(v_err[~hard_mask].max()) > 1.0:
-        raise SystemExit("verification pass: planted offset not recovered (max error %.3f samples)"
-                         % float(v_err[~hard_mask].max()))
+    # An event whose result is more than one sample from the planted offset is held against the CPU oracle: with
+    # 20 dB of noise on a smooth signal the true minimum can sit a sample beside the planted one (seen at 24 kHz);
+    # it passes only if the oracle finds the very same position.
+    off_planted = [int(k) for k in np.nonzero((v_err > 1.0) & ~hard_mask)[0]]
+    beyond_planted = {"events": len(off_planted), "confirmed_by_oracle": 0}
+    if off_planted and rank == 0:
+        if len(off_planted) > 32:
+            raise SystemExit("verification pass: planted offset not recovered on %d events (max error %.3f samples)"
+                             % (len(off_planted), float(v_err[~hard_mask].max())))
+        _cpu_ctx.update(dst=dst.data[0], src=src.data[0], offs=offs, lens=lens, wst=wst, npos=npos)
+        for k in off_planted:
+            o_idx, o_score, _ = _cpu_one(k)
+            if o_idx != int(v_idx[k]):
+                raise SystemExit("verification pass: event %d: position %d, oracle %d, planted offset missed by %.3f samples"
+                                 % (k, int(v_idx[k]), o_idx, float(v_err[k])))
+            beyond_planted["confirmed_by_oracle"] += 1
     for _ in range(args.warmup):
         step()
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -377,6 +390,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity": {"max_shift_err_samples_vs_planted": max_shift_err_vs_planted,
+                       "events_beyond_one_sample_of_planted": beyond_planted,
                        "oracle_sample_searches": len(cpu_results),
                        "max_idx_err_vs_oracle_sample": max_idx_err_vs_oracle,
                        "max_score_err_over_tolerance_vs_oracle_sample": max_rel_score_err,

@@ -27,4 +27,5 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_
 cp gpurun_out/prof_kt/kt_kernel_stats.csv $O/cfg2_kernel_stats.csv; cp gpurun_out/prof_kt/kt_domain_stats.csv $O/cfg2_domain_stats.csv
 python tools/summarize_pmc.py $O/cfg2_pmc_summary.csv $(find gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_sq1 gpurun_out/prof_sq2 -name '*counter_collection.csv')
 head -8 $O/cfg2_kernel_stats.csv; grep -E "kernel|mac|ifft" $O/cfg2_pmc_summary.csv
+rm -rf gpurun_out/prof_hard; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_hard -o hard -- python bench.py --hard-frac 0.05 --steps 3 --warmup 1 --no-cpu-baseline > $O/hard_kt.log 2>&1; cp gpurun_out/prof_hard/hard_kernel_stats.csv $O/cfg2_hard_kernel_stats.csv; head -9 $O/cfg2_hard_kernel_stats.csv
 timeout 300 python tools/latency.py > $O/latency.json 2> $O/latency.err; tail -c 600 $O/latency.json
