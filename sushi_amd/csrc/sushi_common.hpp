@@ -155,10 +155,13 @@ __host__ __device__ inline FftLayout fft_layout(int64_t win_start, int n_pos, in
     return l;
 }
 
-// segment-count class of a search: the smallest SMAX (a multiple of FFT_STEP) that holds the whole pattern;
-// longer patterns use the largest class and several chunks
-constexpr int MAC_CLASSES = 3;
-__host__ __device__ inline int mac_class_smax(int c) { return FFT_STEP * (c + 1); }
+// segment-count class of a search: the smallest SMAX (a multiple of FFT_STEP) that holds the whole pattern.  Classes
+// 0 .. MAC_SHORT_CLASSES-1 (up to 18 segments) run in mac_kernel, the others (up to 36) in mac_long_kernel, which keeps
+// twice the pattern spectra per lane at a lower occupancy; still longer patterns use the largest class and several
+// chunks of its SMAX segments, the output accumulating.
+constexpr int MAC_CLASSES = 6;
+constexpr int MAC_SHORT_CLASSES = 3;
+__host__ __device__ constexpr int mac_class_smax(int c) { return FFT_STEP * (c + 1); }
 __host__ __device__ inline int mac_class(int n_seg) {
     for (int c = 0; c < MAC_CLASSES - 1; ++c)
         if (n_seg <= mac_class_smax(c)) return c;

@@ -405,6 +405,39 @@ def test_fft_spectra_match_numpy():
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.uint8])
+def test_fft_every_segment_count_class_and_chunked_patterns(oracle, dtype):
+    """Patterns of 1 .. 74 segments in one batch: every class of mac_kernel (up to 6 / 12 / 18 segments) and of
+    mac_long_kernel (24 / 30 / 36), and patterns beyond 36 segments, which take several accumulating passes; mixed in one
+    batch so that waves hold searches of different lengths.  All identical to the oracle."""
+    rng = np.random.default_rng(29)
+    n_dst, n_src = 700000, 400000
+    if dtype == np.uint8:
+        dst = rng.integers(0, 256, n_dst, dtype=np.uint8)
+        src = rng.integers(0, 256, n_src, dtype=np.uint8)
+    else:
+        dst = (rng.standard_normal(n_dst) * 0.2 + 0.5).clip(0, 1).astype(np.float32)
+        src = (rng.standard_normal(n_src) * 0.2 + 0.5).clip(0, 1).astype(np.float32)
+    src[5000:5000 + 160000] = dst[300000:460000]                # a 160,000-sample (40-segment) planted copy
+    lens = [1, 4096, 4097, 24576, 24577, 49152, 73728, 73729, 98304, 98305, 122880, 122881, 147456, 147457, 160000,
+            300000, 90000, 140000]
+    offs = [7, 100, 5000, 5000, 200, 5000, 5000, 300, 5000, 5000, 5000, 400, 5000, 5000, 5000, 60000, 250000, 5000]
+    wst = [1000, 250000, 290000, 200000, 0, 250000, 100000, 5000, 250000, 280000, 200000, 30000, 290000, 250000, 200000,
+           350000, 123456, 295000]
+    npos = [50000, 100001, 20000, 150000, 60001, 100000, 300001, 44444, 80000, 30001, 150000, 70001, 20001, 100000, 200001,
+            50001, 77777, 10001]
+    assert all(w + p + m - 1 <= n_dst and o + m <= n_src for w, p, m, o in zip(wst, npos, lens, offs))
+    (idx, score), b = _run_batch(dst, src, offs, lens, wst, npos, "fft", want_batch=True)
+    chk = _check_u8 if dtype == np.uint8 else _check_f32
+    for k in range(len(offs)):
+        res = oracle.match_template(dst[wst[k]:wst[k] + npos[k] + lens[k] - 1], src[offs[k]:offs[k] + lens[k]])[0]
+        chk(res, idx[k], score[k])
+    assert wst[14] + idx[14] == 300000 and wst[8] + idx[8] == 300000       # the planted copy, whole and in part
+    # one search per sub-batch: the same bits
+    (idx2, score2), _ = _run_batch(dst, src, offs, lens, wst, npos, "fft", want_batch=True, workspace_bytes=1)
+    assert (idx2 == idx).all() and (score2.view(np.uint32) == score.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint8])
 def test_fft_long_template_stream_end_and_subbatches(oracle, dtype):
     """Templates longer than 16 segments (chunked accumulate), windows that run into the end of the
     stream (zero blocks), and a workspace so small that the batch is split into many sub-batches:
