@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SUSHI_HIP_ABI_VERSION 5
+#define SUSHI_HIP_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define SUSHI_HIP_API __attribute__((visibility("default")))
@@ -55,6 +55,10 @@ extern "C" {
 /* how a batch is matched.  Both give the same results (tests/test_gpu_parity.py). */
 #define SUSHI_HIP_PATH_FFT 0     /* overlap-save FFT ranking + exact float64 evaluation of the near-minimum positions */
 #define SUSHI_HIP_PATH_DIRECT 1  /* exact-f32 MFMA sliding dot product, O(P*M) */
+
+/* what cv2.matchTemplate's `method` argument selects (and which extremum the caller takes) */
+#define SUSHI_HIP_METHOD_SQDIFF_NORMED 0  /* cv2.TM_SQDIFF_NORMED + argmin: what wav.py:185-186 does; both paths */
+#define SUSHI_HIP_METHOD_CCOEFF_NORMED 1  /* cv2.TM_CCOEFF_NORMED + argmax (BASELINE.json's wording); direct path only */
 
 SUSHI_HIP_API int sushi_hip_abi_version(void);
 SUSHI_HIP_API const char* sushi_hip_strerror(int code);
@@ -148,6 +152,10 @@ SUSHI_HIP_API int sushi_hip_batch_create(const SushiHipStream* dst, const SushiH
                                          size_t workspace_cap_bytes, void* mem_dev, size_t mem_bytes,
                                          void* hip_stream, SushiHipBatch** out);
 SUSHI_HIP_API int sushi_hip_batch_info(const SushiHipBatch* batch, SushiHipBatchInfo* info);
+/* Matching method of the following runs (default after create: SUSHI_HIP_METHOD_SQDIFF_NORMED).
+ * SUSHI_HIP_METHOD_CCOEFF_NORMED: out_idx = first index of the MAXIMUM of cv2.matchTemplate(..., TM_CCOEFF_NORMED),
+ * out_score = that float32; EINVAL on an FFT-path batch. */
+SUSHI_HIP_API int sushi_hip_batch_set_method(SushiHipBatch* batch, int method);
 /* One pass of the hot path over the batch (asynchronous):
  *   out_idx_dev[n]   = result.argmin(axis=1)[0]        (wav.py:186)
  *   out_score_dev[n] = result[0][min_idx], float32     (wav.py:188)

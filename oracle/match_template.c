@@ -198,6 +198,172 @@ ORACLE_API int oracle_definition_sqdiff_normed_f32(const float *img, int64_t L, 
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * TM_CCOEFF_NORMED (BASELINE.json's prose names it; the reference itself calls TM_SQDIFF_NORMED).
+ * templmatch.cpp common_matchTemplate() with numType == 1, isNormed:
+ *     meanStdDev(templ, templMean, templSdv);  templNorm = templSdv^2
+ *     if (templNorm < DBL_EPSILON) { result = Scalar::all(1); return; }
+ *     templNorm = sqrt(templNorm) / sqrt(invArea)
+ *     per position:  num = corr;  t = wndSum;  wndMean2 = t*t*invArea;  num -= t*templMean
+ *                    wndSum2 = window sum of squares;  diff2 = MAX(wndSum2 - wndMean2, 0)
+ *                    t = diff2 <= MIN(0.5, 10*FLT_EPSILON*wndSum2) ? 0 : sqrt(diff2)*templNorm
+ *                    |num| < t ? num/t : (|num| < 1.125 t ? +-1 : 0)
+ * and the caller takes the arg-MAX (first index).  Same status as the rest of this file: parity unpinned.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { double mean, norm; int flat; } ccoeff_templ;
+
+static ccoeff_templ ccoeff_templ_stats(double sum, double sqsum, int64_t M)
+{
+    ccoeff_templ t;
+    double invArea = 1.0 / (double)M;
+    double mean = sum * invArea;
+    double var = sqsum * invArea - mean * mean;
+    if (var < 0) var = 0;
+    double sdv = sqrt(var);
+    double norm = sdv * sdv;                      /* templNorm = templSdv[0]^2 */
+    t.flat = norm < DBL_EPSILON;                  /* result = Scalar::all(1)    */
+    norm = sqrt(norm);
+    norm /= sqrt(invArea);
+    t.mean = mean;
+    t.norm = norm;
+    return t;
+}
+
+static inline float finish_ccoeff_normed(double corr, double wndSum, double wndSqSum, const ccoeff_templ *ts,
+                                         int64_t M, int corr_f32)
+{
+    if (ts->flat) return 1.0f;
+    double invArea = 1.0 / (double)M;
+    double num = corr_f32 ? (double)(float)corr : corr;  /* double num = rrow[j] */
+    double t = wndSum;
+    double wndMean2 = t * t;
+    num -= t * ts->mean;
+    wndMean2 *= invArea;
+    double wndSum2 = wndSqSum;
+    double diff2 = wndSum2 - wndMean2;
+    if (diff2 < 0) diff2 = 0;
+    double lim = 10 * (double)FLT_EPSILON * wndSum2;
+    if (lim > 0.5) lim = 0.5;
+    if (diff2 <= lim)
+        t = 0;
+    else
+        t = sqrt(diff2) * ts->norm;
+    if (fabs(num) < t)
+        num /= t;
+    else if (fabs(num) < t * 1.125)
+        num = num > 0 ? 1 : -1;
+    else
+        num = 0;                                         /* method != SQDIFF_NORMED */
+    return (float)num;
+}
+
+ORACLE_API int oracle_match_ccoeff_normed_f32(const float *img, int64_t L, const float *tmpl, int64_t M,
+                                              float *out, int corr_f32)
+{
+    if (M <= 0 || L < M) return -1;
+    int64_t P = L - M + 1;
+    double *s1 = (double *)malloc((size_t)(L + 1) * sizeof(double));
+    double *sq = (double *)malloc((size_t)(L + 1) * sizeof(double));
+    if (!s1 || !sq) { free(s1); free(sq); return -2; }
+    s1[0] = sq[0] = 0;
+    for (int64_t k = 0; k < L; k++) { s1[k + 1] = s1[k] + (double)img[k]; sq[k + 1] = sq[k] + (double)img[k] * (double)img[k]; }
+    double ts = 0, ts2 = 0;
+    for (int64_t m = 0; m < M; m++) { ts += tmpl[m]; ts2 += (double)tmpl[m] * (double)tmpl[m]; }
+    ccoeff_templ tst = ccoeff_templ_stats(ts, ts2, M);
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < P; p++) {
+        const float *w = img + p;
+        double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        int64_t m = 0;
+        for (; m + 4 <= M; m += 4) {
+            c0 += (double)tmpl[m] * (double)w[m];
+            c1 += (double)tmpl[m + 1] * (double)w[m + 1];
+            c2 += (double)tmpl[m + 2] * (double)w[m + 2];
+            c3 += (double)tmpl[m + 3] * (double)w[m + 3];
+        }
+        for (; m < M; m++) c0 += (double)tmpl[m] * (double)w[m];
+        double corr = (c0 + c1) + (c2 + c3);
+        out[p] = finish_ccoeff_normed(corr, s1[p + M] - s1[p], sq[p + M] - sq[p], &tst, M, corr_f32);
+    }
+    free(s1); free(sq);
+    return 0;
+}
+
+ORACLE_API int oracle_match_ccoeff_normed_u8(const uint8_t *img, int64_t L, const uint8_t *tmpl, int64_t M,
+                                             float *out, int corr_f32)
+{
+    if (M <= 0 || L < M) return -1;
+    int64_t P = L - M + 1;
+    double *s1 = (double *)malloc((size_t)(L + 1) * sizeof(double));
+    double *sq = (double *)malloc((size_t)(L + 1) * sizeof(double));
+    if (!s1 || !sq) { free(s1); free(sq); return -2; }
+    s1[0] = sq[0] = 0;
+    for (int64_t k = 0; k < L; k++) { s1[k + 1] = s1[k] + (double)img[k]; sq[k + 1] = sq[k] + (double)((int)img[k] * (int)img[k]); }
+    int64_t ts = 0, ts2 = 0;
+    for (int64_t m = 0; m < M; m++) { ts += tmpl[m]; ts2 += (int)tmpl[m] * (int)tmpl[m]; }
+    ccoeff_templ tst = ccoeff_templ_stats((double)ts, (double)ts2, M);
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < P; p++) {
+        const uint8_t *w = img + p;
+        int64_t c = 0;
+        for (int64_t m = 0; m < M; m++) c += (int)tmpl[m] * (int)w[m];
+        out[p] = finish_ccoeff_normed((double)c, s1[p + M] - s1[p], sq[p + M] - sq[p], &tst, M, corr_f32);
+    }
+    free(s1); free(sq);
+    return 0;
+}
+
+/* Post-processing only (corr from an FFT): the large-size path of oracle.py. */
+ORACLE_API int oracle_finish_ccoeff_normed(const double *corr, const double *s1_prefix, const double *sq_prefix,
+                                           int64_t P, int64_t M, double templ_sum, double templ_sqsum, float *out,
+                                           int corr_f32)
+{
+    if (M <= 0 || P <= 0) return -1;
+    ccoeff_templ tst = ccoeff_templ_stats(templ_sum, templ_sqsum, M);
+    for (int64_t p = 0; p < P; p++)
+        out[p] = finish_ccoeff_normed(corr[p], s1_prefix[p + M] - s1_prefix[p], sq_prefix[p + M] - sq_prefix[p], &tst, M,
+                                      corr_f32);
+    return 0;
+}
+
+/* first index of the maximum (NumPy argmax) */
+ORACLE_API int64_t oracle_argmax_f32(const float *v, int64_t n)
+{
+    int64_t best = 0;
+    for (int64_t k = 1; k < n; k++)
+        if (v[k] > v[best]) best = k;
+    return best;
+}
+
+/* The definition: R = sum (T-Tm)(I-Im) / sqrt(sum (T-Tm)^2 * sum (I-Im)^2) in long double; 1 for a flat template
+ * (cv2's early return), 0 for a flat window. */
+ORACLE_API int oracle_definition_ccoeff_normed_f32(const float *img, int64_t L, const float *tmpl, int64_t M,
+                                                   double *out)
+{
+    if (M <= 0 || L < M) return -1;
+    int64_t P = L - M + 1;
+    long double tm = 0;
+    for (int64_t m = 0; m < M; m++) tm += tmpl[m];
+    tm /= M;
+    long double t2 = 0;
+    for (int64_t m = 0; m < M; m++) t2 += (tmpl[m] - tm) * (tmpl[m] - tm);
+    for (int64_t p = 0; p < P; p++) {
+        long double im = 0;
+        for (int64_t m = 0; m < M; m++) im += img[p + m];
+        im /= M;
+        long double c = 0, i2 = 0;
+        for (int64_t m = 0; m < M; m++) {
+            long double t = tmpl[m] - tm, i = img[p + m] - im;
+            c += t * i;
+            i2 += i * i;
+        }
+        if (t2 / M < DBL_EPSILON) { out[p] = 1.0; continue; }
+        long double den = sqrtl(t2 * i2);
+        out[p] = den > 0 ? (double)(c / den) : 0.0;
+    }
+    return 0;
+}
+
 ORACLE_API int oracle_num_threads(void)
 {
 #ifdef _OPENMP

@@ -59,6 +59,12 @@ def _load():
         lib.oracle_argmin_f32.argtypes = [vp, i64]
         lib.oracle_argmin_f32.restype = i64
         lib.oracle_definition_sqdiff_normed_f32.argtypes = [vp, i64, vp, i64, vp]
+        lib.oracle_match_ccoeff_normed_f32.argtypes = [vp, i64, vp, i64, vp, ci]
+        lib.oracle_match_ccoeff_normed_u8.argtypes = [vp, i64, vp, i64, vp, ci]
+        lib.oracle_finish_ccoeff_normed.argtypes = [vp, vp, vp, i64, i64, ctypes.c_double, ctypes.c_double, vp, ci]
+        lib.oracle_argmax_f32.argtypes = [vp, i64]
+        lib.oracle_argmax_f32.restype = i64
+        lib.oracle_definition_ccoeff_normed_f32.argtypes = [vp, i64, vp, i64, vp]
         lib.oracle_num_threads.restype = ci
         _lib = lib
     return _lib
@@ -81,8 +87,11 @@ def _as_row(a, dtype=None):
     return np.ascontiguousarray(a)
 
 
-def match_template_direct(search, templ, corr_f32: bool = True) -> np.ndarray:
-    """cv2.matchTemplate(search, templ, cv2.TM_SQDIFF_NORMED) -> (1, P) float32, direct O(P*M) in C."""
+SQDIFF_NORMED, CCOEFF_NORMED = "sqdiff_normed", "ccoeff_normed"      # cv2.TM_SQDIFF_NORMED (what wav.py:185 passes), cv2.TM_CCOEFF_NORMED
+
+
+def match_template_direct(search, templ, corr_f32: bool = True, method: str = SQDIFF_NORMED) -> np.ndarray:
+    """cv2.matchTemplate(search, templ, cv2.TM_SQDIFF_NORMED | TM_CCOEFF_NORMED) -> (1, P) float32, direct O(P*M) in C."""
     s = _as_row(search)
     t = _as_row(templ, s.dtype)
     L, M = s.shape[0], t.shape[0]
@@ -90,10 +99,13 @@ def match_template_direct(search, templ, corr_f32: bool = True) -> np.ndarray:
         raise ValueError("template larger than search image (cv2.error in the reference)")
     out = np.empty(L - M + 1, np.float32)
     lib = _load()
+    if method not in (SQDIFF_NORMED, CCOEFF_NORMED):
+        raise ValueError("unknown method %r" % (method,))
+    stem = "oracle_match_" + method
     if s.dtype == np.float32:
-        fn = lib.oracle_match_sqdiff_normed_f32
+        fn = getattr(lib, stem + "_f32")
     elif s.dtype == np.uint8:
-        fn = lib.oracle_match_sqdiff_normed_u8
+        fn = getattr(lib, stem + "_u8")
     else:
         raise TypeError("sample type must be float32 or uint8 (wav.py:109)")
     rc = fn(s.ctypes.data, L, t.ctypes.data, M, out.ctypes.data, int(corr_f32))
@@ -115,7 +127,7 @@ def cross_correlate_fft(search_row: np.ndarray, templ_row: np.ndarray) -> np.nda
     return corr
 
 
-def match_template_fft(search, templ, corr_f32: bool = True) -> np.ndarray:
+def match_template_fft(search, templ, corr_f32: bool = True, method: str = SQDIFF_NORMED) -> np.ndarray:
     """Same result as match_template_direct, O(L log M): FFT cross-correlation +
     the C epilogue (common_matchTemplate restatement)."""
     s = _as_row(search)
@@ -130,21 +142,47 @@ def match_template_fft(search, templ, corr_f32: bool = True) -> np.ndarray:
     np.cumsum(s64 * s64, out=sq[1:])          # integral(..., sqsum, CV_64F)
     t64 = t.astype(np.float64)
     out = np.empty(P, np.float32)
-    rc = _load().oracle_finish_sqdiff_normed(corr.ctypes.data, sq.ctypes.data, P, M,
-                                             float(t64.sum()), float((t64 * t64).sum()),
-                                             out.ctypes.data, int(corr_f32))
+    if method == CCOEFF_NORMED:
+        s1 = np.zeros(L + 1, np.float64)
+        np.cumsum(s64, out=s1[1:])            # integral(..., sum, sqsum, CV_64F)
+        rc = _load().oracle_finish_ccoeff_normed(corr.ctypes.data, s1.ctypes.data, sq.ctypes.data, P, M,
+                                                 float(t64.sum()), float((t64 * t64).sum()),
+                                                 out.ctypes.data, int(corr_f32))
+    elif method == SQDIFF_NORMED:
+        rc = _load().oracle_finish_sqdiff_normed(corr.ctypes.data, sq.ctypes.data, P, M,
+                                                 float(t64.sum()), float((t64 * t64).sum()),
+                                                 out.ctypes.data, int(corr_f32))
+    else:
+        raise ValueError("unknown method %r" % (method,))
     if rc != 0:
         raise RuntimeError("oracle error %d" % rc)
     return out.reshape(1, -1)
 
 
-def match_template(search, templ, corr_f32: bool = True) -> np.ndarray:
+def match_template(search, templ, corr_f32: bool = True, method: str = SQDIFF_NORMED) -> np.ndarray:
     """Dispatch on size: direct C below ~2e9 MACs, FFT above."""
     s = _as_row(search)
     t = _as_row(templ)
     if (s.shape[0] - t.shape[0] + 1) * t.shape[0] <= 2_000_000_000:
-        return match_template_direct(s, t, corr_f32)
-    return match_template_fft(s, t, corr_f32)
+        return match_template_direct(s, t, corr_f32, method)
+    return match_template_fft(s, t, corr_f32, method)
+
+
+def definition_ccoeff_normed(search, templ) -> np.ndarray:
+    """sum (T-mean T)(I-mean I) / sqrt(sum (T-mean T)^2 sum (I-mean I)^2) in long double, no shared helper."""
+    s = _as_row(search).astype(np.float32)
+    t = _as_row(templ).astype(np.float32)
+    out = np.empty(s.shape[0] - t.shape[0] + 1, np.float64)
+    rc = _load().oracle_definition_ccoeff_normed_f32(s.ctypes.data, s.shape[0], t.ctypes.data, t.shape[0], out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("oracle error %d" % rc)
+    return out
+
+
+def argmax_first(result_row: np.ndarray) -> int:
+    """result.argmax(axis=1)[0]: first index of the maximum."""
+    r = np.ascontiguousarray(np.asarray(result_row, np.float32).reshape(-1))
+    return int(_load().oracle_argmax_f32(r.ctypes.data, r.shape[0]))
 
 
 def definition_sqdiff_normed(search, templ) -> np.ndarray:

@@ -17,9 +17,11 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sushi_hip.h")
 # dtype codes / paths (include/sushi_hip.h)
 U8, F32 = 0, 1
 PATH_FFT, PATH_DIRECT = 0, 1
+METHOD_SQDIFF_NORMED, METHOD_CCOEFF_NORMED = 0, 1       # cv2.TM_SQDIFF_NORMED + argmin (wav.py:185-186) | cv2.TM_CCOEFF_NORMED + argmax
+METHODS = {"sqdiff_normed": METHOD_SQDIFF_NORMED, "ccoeff_normed": METHOD_CCOEFF_NORMED}
 VIEW_XC, VIEW_S1, VIEW_S2, VIEW_UREL, VIEW_BASE, VIEW_SPECTRA = range(6)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 NSTAGES = 5
 STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish")
 STAGE_KERNELS = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "ifft_kernel", "refine": "refine_kernel",
@@ -98,6 +100,8 @@ def lib():
     L.sushi_hip_batch_create.argtypes = [vp, vp, vp, ci, ci, ci, sz, vp, sz, vp, pvp]
     L.sushi_hip_batch_info.restype = ci
     L.sushi_hip_batch_info.argtypes = [vp, ctypes.POINTER(BatchInfo)]
+    L.sushi_hip_batch_set_method.restype = ci
+    L.sushi_hip_batch_set_method.argtypes = [vp, ci]
     L.sushi_hip_batch_run.restype = ci
     L.sushi_hip_batch_run.argtypes = [vp, dbl, vp, vp, vp]
     L.sushi_hip_batch_diagnostics.restype = ci

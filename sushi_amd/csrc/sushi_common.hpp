@@ -82,6 +82,18 @@ __device__ __forceinline__ unsigned long long make_key(float score, unsigned pos
 }
 __device__ __forceinline__ float key_score(unsigned long long key) { return __uint_as_float((unsigned)(key >> 32)); }
 __device__ __forceinline__ unsigned key_pos(unsigned long long key) { return (unsigned)(key & 0xffffffffull); }
+// arg-MAX through the same atomicMin (TM_CCOEFF_NORMED, scores in [-1, 1]): the key holds -score under the usual
+// order-preserving map of float bits to unsigned, so the smallest key is the largest score at its lowest position.
+__device__ __forceinline__ unsigned long long make_key_max(float score, unsigned pos) {
+    const unsigned b = __float_as_uint(-(score + 0.0f));                  // + 0.0f: -0.0 and 0.0 tie, as in NumPy
+    const unsigned u = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((unsigned long long)u << 32) | pos;
+}
+__device__ __forceinline__ float key_score_max(unsigned long long key) {
+    const unsigned u = (unsigned)(key >> 32);
+    const unsigned b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return -__uint_as_float(b);
+}
 
 // Template statistics in the order cv2 derives them (templmatch.cpp common_matchTemplate:
 // meanStdDev -> templSum2 / templNorm), from the float64 prefix sums of the source stream's samples
@@ -89,7 +101,9 @@ __device__ __forceinline__ unsigned key_pos(unsigned long long key) { return (un
 struct TemplStats {
     double tS1;           // sum T
     double cM;            // centre^2 * M (what the direct kernel's centred cross term has to be corrected by)
-    double tU, tnorm;     // templSum2, templNorm as cv2 has them
+    double tU, tnorm;     // templSum2, templNorm as cv2 has them (TM_SQDIFF_NORMED: numType != 1)
+    double tmean, tnorm_c; // templMean, templNorm of TM_CCOEFF_NORMED (numType == 1)
+    bool flat;            // templSdv^2 < DBL_EPSILON: cv2 returns a result of all ones for TM_CCOEFF_NORMED
 };
 
 __device__ __forceinline__ TemplStats templ_stats(const double* __restrict__ s1, const double* __restrict__ s2,
@@ -106,6 +120,9 @@ __device__ __forceinline__ TemplStats templ_stats(const double* __restrict__ s1,
     const double t_norm2 = t_sdv * t_sdv + t_mean * t_mean;          // templSum2 before "/= invArea"
     t.tU = t_norm2 / invArea;                                        // templSum2
     t.tnorm = sqrt(t_norm2) / sqrt(invArea);                         // templNorm
+    t.tmean = t_mean;
+    t.flat = t_sdv * t_sdv < DBL_EPSILON;
+    t.tnorm_c = sqrt(t_sdv * t_sdv) / sqrt(invArea);
     return t;
 }
 
@@ -125,6 +142,29 @@ __device__ __forceinline__ float finish_sqdiff_normed(double corr_u, double wU, 
     return (float)r;
 }
 
+// OpenCV templmatch.cpp common_matchTemplate(), TM_CCOEFF_NORMED branch (numType == 1, isNormed), one position.
+// corr_u: sum T*I, wS1 / wU: sum I, sum I^2 over the window.  (BASELINE.json names this method; the reference calls
+// TM_SQDIFF_NORMED.  The caller takes the first arg-MAX.)
+__device__ __forceinline__ float finish_ccoeff_normed(double corr_u, double wS1, double wU, const TemplStats& ts, int M) {
+    if (ts.flat) return 1.0f;
+    const double invArea = 1.0 / (double)M;
+    double num = (double)(float)corr_u;          // cv2 keeps corr in its float32 result Mat
+    double t = wS1;
+    double wndMean2 = t * t;
+    num -= t * ts.tmean;
+    wndMean2 *= invArea;
+    double diff2 = wU - wndMean2;
+    diff2 = diff2 > 0.0 ? diff2 : 0.0;
+    double lim = 10.0 * (double)FLT_EPSILON * wU;
+    lim = lim < 0.5 ? lim : 0.5;
+    t = (diff2 <= lim) ? 0.0 : sqrt(diff2) * ts.tnorm_c;
+    double r;
+    if (fabs(num) < t) r = num / t;
+    else if (fabs(num) < t * 1.125) r = num > 0.0 ? 1.0 : -1.0;
+    else r = 0.0;
+    return (float)r;
+}
+
 // Score of one position from the cross term of the CENTRED samples xc = x - centre (what the direct MFMA
 // kernel accumulates) and the float64 prefix sums (w1, w2: the destination stream's, offset to the window):
 // sum T*I = sum T'I' + centre * (sum T + sum I) - centre^2 * M.  Returns the float32 cv2 would store at result[0][p].
@@ -135,6 +175,14 @@ __device__ __forceinline__ float score_at(double corr_c, const TemplStats& t, do
     const double wU = w2[p + M] - w2[p];                             // sum I^2 over the window
     const double corr_u = corr_c + centre * (t.tS1 + wS1) - t.cM;    // sum T*I
     return finish_sqdiff_normed(corr_u, wU, t.tU, t.tnorm);
+}
+__device__ __forceinline__ float score_ccoeff_at(double corr_c, const TemplStats& t, double centre,
+                                                 const double* __restrict__ w1, const double* __restrict__ w2,
+                                                 int64_t p, int M) {
+    const double wS1 = w1[p + M] - w1[p];
+    const double wU = w2[p + M] - w2[p];
+    const double corr_u = corr_c + centre * (t.tS1 + wS1) - t.cM;
+    return finish_ccoeff_normed(corr_u, wS1, wU, t, M);
 }
 
 // Score of one position from the exact cross term of the samples themselves (refine_kernel).

@@ -59,6 +59,7 @@ struct MatchArgs {
     const SearchDesc* searches;
     int n_search;
     int n_tiles;
+    int method;                   // SUSHI_HIP_METHOD_*
     unsigned long long* keys;
 };
 
@@ -194,8 +195,9 @@ __device__ __forceinline__ void match_tile(const MatchArgs& a, const int s_idx, 
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int p = p0 + wb + 1024 * b + 32 * row + i;
                 if (p < P) {
-                    const float score = score_at(acc2[b][r], ts, a.centre, w1, w2, p, M);
-                    const unsigned long long key = make_key(score, (unsigned)p);
+                    const unsigned long long key = a.method == SUSHI_HIP_METHOD_CCOEFF_NORMED
+                        ? make_key_max(score_ccoeff_at(acc2[b][r], ts, a.centre, w1, w2, p, M), (unsigned)p)
+                        : make_key(score_at(acc2[b][r], ts, a.centre, w1, w2, p, M), (unsigned)p);
                     best = key < best ? key : best;
                 }
             }
@@ -341,13 +343,13 @@ void exact_tiles_kernel(TileParams a) {
     }
 }
 
-__global__ void unpack_keys_kernel(const unsigned long long* __restrict__ keys, int n,
+__global__ void unpack_keys_kernel(const unsigned long long* __restrict__ keys, int n, int method,
                                    int32_t* __restrict__ out_idx, float* __restrict__ out_score) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) {
         const unsigned long long key = keys[k];
-        out_idx[k] = (int32_t)(unsigned)(key & 0xffffffffull);
-        out_score[k] = __uint_as_float((unsigned)(key >> 32));
+        out_idx[k] = (int32_t)key_pos(key);
+        out_score[k] = method == SUSHI_HIP_METHOD_CCOEFF_NORMED ? key_score_max(key) : key_score(key);
     }
 }
 
@@ -669,27 +671,30 @@ int direct_variant_tile(int variant) {
     return kVariants[variant].waves * kVariants[variant].nb * 1024;
 }
 
-int launch_unpack(const unsigned long long* keys_dev, int n, int32_t* out_idx_dev, float* out_score_dev, hipStream_t st) {
-    hipLaunchKernelGGL(unpack_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, keys_dev, n, out_idx_dev, out_score_dev);
+int launch_unpack(const unsigned long long* keys_dev, int n, int method, int32_t* out_idx_dev, float* out_score_dev,
+                  hipStream_t st) {
+    hipLaunchKernelGGL(unpack_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, keys_dev, n, method, out_idx_dev,
+                       out_score_dev);
     return launch_ok();
 }
 
-int launch_direct(const StreamRefs& r, const SearchDesc* searches_dev, int n_search, int n_tiles, int variant,
+int launch_direct(const StreamRefs& r, const SearchDesc* searches_dev, int n_search, int n_tiles, int variant, int method,
                   unsigned long long* keys_dev, int32_t* out_idx_dev, float* out_score_dev, hipStream_t st) {
     if (n_tiles < n_search || variant < 0 || variant >= kNumVariants) return SUSHI_HIP_EINVAL;
+    if (method != SUSHI_HIP_METHOD_SQDIFF_NORMED && method != SUSHI_HIP_METHOD_CCOEFF_NORMED) return SUSHI_HIP_EINVAL;
     if (hipMemsetAsync(keys_dev, 0xff, (size_t)n_search * sizeof(uint64_t), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
     MatchArgs a;
     a.dst_xc = r.dst_xc; a.dst_s1 = r.dst_s1; a.dst_s2 = r.dst_s2; a.dst_len = r.dst_len;
     a.src_xc = r.src_xc; a.src_s1 = r.src_s1; a.src_s2 = r.src_s2; a.src_len = r.src_len;
     a.centre = r.centre; a.searches = searches_dev; a.n_search = n_search; a.n_tiles = n_tiles;
-    a.keys = keys_dev;
+    a.keys = keys_dev; a.method = method;
     switch (variant) {
         case 0: hipLaunchKernelGGL((match_sqdiff_f32_kernel<1, 1>), dim3(n_tiles), dim3(64), 0, st, a); break;
         case 1: hipLaunchKernelGGL((match_sqdiff_f32_kernel<4, 1>), dim3(n_tiles), dim3(256), 0, st, a); break;
         default: hipLaunchKernelGGL((match_sqdiff_f32_kernel<4, 4>), dim3(n_tiles), dim3(256), 0, st, a); break;
     }
     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-    return launch_unpack(keys_dev, n_search, out_idx_dev, out_score_dev, st);
+    return launch_unpack(keys_dev, n_search, method, out_idx_dev, out_score_dev, st);
 }
 
 int launch_refine(const RefineParams& p, hipStream_t st) {

@@ -69,7 +69,7 @@ int direct_variant_count();
 int direct_variant_tile(int variant);
 
 // direct path: one launch of the MFMA kernel + unpack
-int launch_direct(const StreamRefs& r, const SearchDesc* searches_dev, int n_search, int n_tiles, int variant,
+int launch_direct(const StreamRefs& r, const SearchDesc* searches_dev, int n_search, int n_tiles, int variant, int method,
                   unsigned long long* keys_dev, int32_t* out_idx_dev, float* out_score_dev, hipStream_t st);
 
 // FFT path, exact stages (sushi_hip.hip):
@@ -99,7 +99,8 @@ struct TileParams {
     RunCounters* counters;            // n_tiles read on the device
 };
 int launch_tiles(const TileParams& p, hipStream_t st);
-int launch_unpack(const unsigned long long* keys_dev, int n, int32_t* out_idx_dev, float* out_score_dev, hipStream_t st);
+int launch_unpack(const unsigned long long* keys_dev, int n, int method, int32_t* out_idx_dev, float* out_score_dev,
+                  hipStream_t st);
 
 }  // namespace sushi
 #endif

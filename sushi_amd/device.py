@@ -151,11 +151,17 @@ class SearchBatch(object):
     path = 'fft' (default): overlap-save FFT scores + exact re-evaluation of the positions that can be the
     minimum; path = 'direct': the exact-f32 MFMA sliding dot product (`variant` picks its tile size).
     Same results either way.
+
+    method = 'sqdiff_normed' (default; cv2.TM_SQDIFF_NORMED + argmin, what wav.py:185-186 does) or 'ccoeff_normed'
+    (cv2.TM_CCOEFF_NORMED + argmax, the method BASELINE.json's wording names; direct path only).
     """
 
     def __init__(self, dst, src, tmpl_off, tmpl_len, win_start, n_pos, variant=None, path=None,
-                 delta=DEFAULT_DELTA, workspace_bytes=None):
+                 delta=DEFAULT_DELTA, workspace_bytes=None, method="sqdiff_normed"):
         self._handle = None
+        if method not in _native.METHODS:
+            raise SushiError("method must be one of %s" % sorted(_native.METHODS))
+        self.method = method
         if dst.device != src.device:
             raise SushiError("dst and src streams live on different devices")
         if dst.dtype != src.dtype:
@@ -182,6 +188,8 @@ class SearchBatch(object):
         self.path = default_path() if path is None else path
         if self.path not in ("fft", "direct"):
             raise SushiError("path must be 'fft' or 'direct'")
+        if method != "sqdiff_normed" and self.path != "direct":
+            raise SushiError("method %r needs path='direct'" % method)
         path_code = _native.PATH_FFT if self.path == "fft" else _native.PATH_DIRECT
         req = np.zeros(n, dtype=_native.REQUEST_DTYPE)
         req["tmpl_off"], req["win_start"], req["tmpl_len"], req["n_pos"] = tmpl_off, win_start, tmpl_len, n_pos
@@ -203,6 +211,7 @@ class SearchBatch(object):
                                           self._mem.data_ptr(), need, _raw_stream(dev), ctypes.byref(h))
             _native.check(rc, "sushi_hip_batch_create")
             self._handle = h
+            _native.check(L.sushi_hip_batch_set_method(h, _native.METHODS[method]), "sushi_hip_batch_set_method")
             self.out_idx = torch.empty(n, dtype=torch.int32, device=dev)
             self.out_score = torch.empty(n, dtype=torch.float32, device=dev)
         info = _native.BatchInfo()

@@ -325,10 +325,12 @@ class WavStream(object):
         lo, hi, _ = slice(start_sample, end_sample).indices(self.data.shape[1])   # NumPy slice truncation
         return start_time, lo, max(hi - lo, 0) - pattern_len + 1
 
-    def find_substreams(self, patterns, window_centers, window_sizes, with_index=False):
+    def find_substreams(self, patterns, window_centers, window_sizes, with_index=False, method="sqdiff_normed"):
         """[find_substream(p, c, w) for p, c, w in zip(...)] in one GPU launch.
         Returns (diffs: float32 ndarray, times: list of float); with_index=True appends the absolute
-        sample index of every match in self.data (what SpeculativeStream caches)."""
+        sample index of every match in self.data (what SpeculativeStream caches).
+        method: 'sqdiff_normed' = what the reference's find_substream computes (wav.py:185-186: TM_SQDIFF_NORMED, argmin);
+        'ccoeff_normed' = cv2.TM_CCOEFF_NORMED with argmax instead (not used by the reference; direct kernel)."""
         from .device import DeviceStream, SearchBatch
         n = len(patterns)
         if not (len(window_centers) == len(window_sizes) == n) or n == 0:
@@ -361,7 +363,10 @@ class WavStream(object):
             start_times.append(st)
             win_start.append(lo)
             n_pos.append(p)
-        batch = SearchBatch(dst_dev, src_dev, offs, lens, win_start, n_pos)
+        if method == "sqdiff_normed":
+            batch = SearchBatch(dst_dev, src_dev, offs, lens, win_start, n_pos)
+        else:
+            batch = SearchBatch(dst_dev, src_dev, offs, lens, win_start, n_pos, path="direct", method=method)
         batch.run()
         idx, score = batch.results()
         times = [st + (int(k) / float(self.sample_rate)) for st, k in zip(start_times, idx)]

@@ -25,7 +25,7 @@ def test_library_builds_and_exports_all_declared_symbols():
 def test_host_only_entry_points():
     L = _native.lib()
     C = ctypes
-    assert L.sushi_hip_abi_version() == 5
+    assert L.sushi_hip_abi_version() == 6
     assert L.sushi_hip_strerror(0) == b"ok" and b"invalid" in L.sushi_hip_strerror(-1)
     assert L.sushi_hip_centre(_native.U8) == 128.0 and L.sushi_hip_centre(_native.F32) == 0.5
     N, B = L.sushi_hip_fft_size(), L.sushi_hip_fft_block()
@@ -43,6 +43,7 @@ def test_host_only_entry_points():
     assert L.sushi_hip_stream_create(C.c_void_p(4096), 1, 10, 0, C.c_void_p(4096 + 8), 1 << 20, None, C.byref(h)) == -2
     assert L.sushi_hip_stream_create(C.c_void_p(4096), 1, 10, 0, C.c_void_p(4096), 16, None, C.byref(h)) == -4
     assert L.sushi_hip_batch_run(None, 2e-5, None, None, None) == -1
+    assert L.sushi_hip_batch_set_method(None, 0) == -1
     assert L.sushi_hip_batch_create(None, None, None, 0, 0, -1, 0, None, 0, None, C.byref(h)) == -1
     assert L.sushi_hip_load_decode(None, 10, 2, 2, None, None) == -1
     assert L.sushi_hip_load_decode(C.c_void_p(4096), 10, 2, 4, C.c_void_p(4096), None) == -1     # wav.py:75-76 sample widths
