@@ -252,22 +252,26 @@ def main():
     ev_starts = np.array([s for s, _ in events])
     v_times = np.array(start_times) + v_idx.cpu().numpy().astype(np.float64) / float(rate)
     v_err = np.abs((v_times - ev_starts) - args.offset) * rate
-    # An event whose result is more than one sample from the planted offset is held against the CPU oracle: with
-    # 20 dB of noise on a smooth signal the true minimum can sit a sample beside the planted one (seen at 24 kHz);
-    # it passes only if the oracle finds the very same position.
+    # An event whose result is more than one sample from the planted offset: with 20 dB of noise on a smooth signal the
+    # true minimum can sit a sample beside the planted one (seen at 24 kHz), on top of the < 1 sample that the two
+    # truncations of wav.py:173-175 contribute.  Beyond two samples the run is refused outright; between one and two the
+    # CPU-baseline leg's oracle (the checker; skipped with --no-cpu-baseline) has to find the very same position.
     off_planted = [int(k) for k in np.nonzero((v_err > 1.0) & ~hard_mask)[0]]
-    beyond_planted = {"events": len(off_planted), "confirmed_by_oracle": 0}
+    use_oracle = world == 1 and not args.no_cpu_baseline
+    beyond_planted = {"events": len(off_planted), "confirmed_by_oracle": 0 if use_oracle else None}
     if off_planted and rank == 0:
-        if len(off_planted) > 32:
+        worst = float(v_err[~hard_mask].max())
+        if len(off_planted) > 32 or worst > 2.0:
             raise SystemExit("verification pass: planted offset not recovered on %d events (max error %.3f samples)"
-                             % (len(off_planted), float(v_err[~hard_mask].max())))
-        _cpu_ctx.update(dst=dst.data[0], src=src.data[0], offs=offs, lens=lens, wst=wst, npos=npos)
-        for k in off_planted:
-            o_idx, o_score, _ = _cpu_one(k)
-            if o_idx != int(v_idx[k]):
-                raise SystemExit("verification pass: event %d: position %d, oracle %d, planted offset missed by %.3f samples"
-                                 % (k, int(v_idx[k]), o_idx, float(v_err[k])))
-            beyond_planted["confirmed_by_oracle"] += 1
+                             % (len(off_planted), worst))
+        if use_oracle:
+            _cpu_ctx.update(dst=dst.data[0], src=src.data[0], offs=offs, lens=lens, wst=wst, npos=npos)
+            for k in off_planted:
+                o_idx, o_score, _ = _cpu_one(k)
+                if o_idx != int(v_idx[k]):
+                    raise SystemExit("verification pass: event %d: position %d, oracle %d, planted offset missed by %.3f "
+                                     "samples" % (k, int(v_idx[k]), o_idx, float(v_err[k])))
+                beyond_planted["confirmed_by_oracle"] += 1
     for _ in range(args.warmup):
         step()
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
