@@ -372,3 +372,13 @@ ORACLE_API int oracle_num_threads(void)
     return 1;
 #endif
 }
+
+/* the bench's CPU leg runs one process per core: each of them single-threaded */
+ORACLE_API void oracle_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
+}

@@ -66,12 +66,44 @@ def _load():
         lib.oracle_argmax_f32.restype = i64
         lib.oracle_definition_ccoeff_normed_f32.argtypes = [vp, i64, vp, i64, vp]
         lib.oracle_num_threads.restype = ci
+        lib.oracle_set_num_threads.argtypes = [ci]
+        lib.oracle_set_num_threads.restype = None
         _lib = lib
     return _lib
 
 
 def num_threads() -> int:
     return int(_load().oracle_num_threads())
+
+
+def set_num_threads(n: int) -> None:
+    """OpenMP threads of the C restatement in this process (bench.py's CPU leg: one process per core, one thread each)."""
+    _load().oracle_set_num_threads(int(n))
+
+
+# --------------------------------------------------------------------------- the real cv2, when there is one
+
+def cv2_module():
+    """`import cv2` if it can be imported, else None.  It cannot in the build image (no OpenCV, no
+    network), which is why parity is unpinned at this boundary; wherever it CAN (a GPU box with OpenCV, a
+    maintainer's machine) tests/test_cv2_crosscheck.py and bench.py's `parity.cv2` field compare the oracle --
+    and the HIP path -- with the call wav.py:185 actually makes."""
+    try:
+        import cv2
+    except Exception:
+        return None
+    return cv2 if hasattr(cv2, "matchTemplate") else None
+
+
+def match_template_cv2(search, templ, method: str = "sqdiff_normed") -> np.ndarray:
+    """wav.py:185 itself: cv2.matchTemplate(search_source, pattern, cv2.TM_SQDIFF_NORMED) -> (1, P) float32."""
+    cv2 = cv2_module()
+    if cv2 is None:
+        raise RuntimeError("cv2 is not importable here")
+    s = _as_row(search)
+    t = _as_row(templ, s.dtype)
+    code = {"sqdiff_normed": cv2.TM_SQDIFF_NORMED, "ccoeff_normed": cv2.TM_CCOEFF_NORMED}[method]
+    return np.asarray(cv2.matchTemplate(s.reshape(1, -1), t.reshape(1, -1), code), np.float32).reshape(1, -1)
 
 
 # --------------------------------------------------------------------------- matchTemplate

@@ -65,7 +65,7 @@ def decode_file_on_device(wavfile, dev):
     frame_size = wavfile.frame_size
     if wavfile.sample_width not in (2, 3):
         raise SushiError('Unsupported sample width: {0}'.format(wavfile.sample_width))
-    frames_total = int(wavfile.frames_count)
+    frames_total = int(wavfile.frames_available)           # never more than the file holds, whatever the header says
     frames_per_chunk = max(1, UPLOAD_CHUNK_BYTES // frame_size)
     with torch.cuda.device(dev):
         st = torch.cuda.current_stream(dev).cuda_stream
@@ -86,7 +86,7 @@ def decode_file_on_device(wavfile, dev):
                                                   mono.data_ptr() + 4 * done, st), "sushi_hip_load_decode")
             done += got
             del staged                                           # stream-ordered free: the kernel above is queued first
-    return mono, done
+    return mono[:max(done, 1)], done                          # the frames that were there (n_raw of the pipeline)
 
 
 def build_on_device(samples, framerate, frames_count, sample_rate, sample_type, device=None, read_chunk_size=1,

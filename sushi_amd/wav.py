@@ -59,6 +59,10 @@ class DownmixedWavFile(object):
                         self.frames_count = (file_size - self._file.tell()) // self.frame_size
                     else:
                         self.frames_count = size // self.frame_size
+                    # what the file really holds: a data size that overstates the file (a truncated file, a
+                    # 0xFFFFFFFF placeholder from a piped encoder) must not size any buffer of raw frames
+                    self.frames_available = max(0, min(self.frames_count,
+                                                       (file_size - self._data_start) // self.frame_size))
                     data_chunk_read = True
                     break
                 else:
@@ -169,15 +173,23 @@ class WavStream(object):
             if self._use_gpu():
                 # decode + downmix on the GPU, the file uploaded in bounded chunks (sushi_amd/load.py)
                 from .load import build_on_device, decode_file_on_device
-                mono, _ = decode_file_on_device(stream, torch_device("cuda" if device is None else device))
+                mono, got = decode_file_on_device(stream, torch_device("cuda" if device is None else device))
+                if got == 0:
+                    raise SushiError('no audio frames in the data chunk')
                 self._dev_row = None
                 self.data, self._dev_row, self.sample_count, self.padding_size = build_on_device(
                     mono, stream.framerate, stream.frames_count, sample_rate, sample_type,
                     read_chunk_size=self.READ_CHUNK_SIZE, padding_seconds=self.PADDING_SECONDS)
                 self.sample_rate = sample_rate
             else:
-                samples = np.zeros(stream.frames_count, np.float32)
-                stream.read_into(samples, 10 * stream.framerate)
+                samples = np.zeros(stream.frames_available, np.float32)
+                got = stream.read_into(samples, 10 * stream.framerate)
+                if got == 0:
+                    raise SushiError('no audio frames in the data chunk')
+                # a file shorter than its header says: the frames that exist are decimated as the reference does (a
+                # short last chunk by its own length, wav.py:127-134); what the reference leaves as uninitialised memory
+                # (np.empty, wav.py:119) is zero here
+                samples = samples[:got]
                 self._build_host(samples, stream.framerate, stream.frames_count, sample_rate, sample_type)
         except Exception as e:
             raise SushiError('Error while loading {0}: {1}'.format(path, e))

@@ -1,0 +1,48 @@
+"""bench.py's N > 1 control flow (sharding, verification verdict on every rank, all-gather, max-over-ranks timing,
+per-rank report via all_gather_object) under torch.distributed.run with two gloo ranks and a stand-in batch: the
+bookkeeping an 8-GPU node will execute has run somewhere before it gets there.  No GPU, nothing measured."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(nproc, extra=()):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--dry-backend", "gloo",
+           "--config", "1", "--events", "25", "--minutes", "3", "--window", "10"] + list(extra)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+
+
+def test_two_rank_dry_run_prints_one_line_with_per_rank_bookkeeping():
+    out = _run(2)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                        # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and "dry_run" in d
+    assert d["config"]["global_events"] == 25 and d["config"]["events_per_gpu"] == [13, 12]
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1] and [r["events"] for r in d["per_rank"]] == [13, 12]
+    assert d["parity"]["max_shift_err_samples_vs_planted"] <= 1.0      # the gathered results are in global order
+    assert d["value"] > 0 and d["cpu_baseline"] is None
+
+
+def test_a_failed_verification_ends_every_rank():
+    """the verdict of the verification pass is reached on every rank (they hold the same gathered results),
+    so a refused run exits all of them instead of leaving ranks > 0 in the next collective."""
+    out = _run(2, ["--offset", "7.25", "--dry-plant-error", "5"])
+    assert out.returncode != 0
+    assert "planted offset not recovered" in (out.stderr + out.stdout)

@@ -487,17 +487,20 @@ def test_fft_near_ties_fall_back_to_direct(oracle):
     assert idx_d[0] == idx[0] and np.float32(score_d[0]) == np.float32(score[0])
 
 
-def _planted_config(seconds, rate, window, n_events, off_s, seed, n_oracle, oracle, min_len=1.0, max_len=5.0):
+def _planted_config(seconds, rate, window, n_events, off_s, seed, n_oracle, oracle, min_len=1.0, max_len=5.0,
+                    sample_type="float32"):
     """Shared body of the full-size configuration tests: planted offset recovered on every event
-    (size-independent property), a few events checked against the FFT oracle, both library paths agree."""
+    (size-independent property), events checked against the FFT oracle (uint8, the reference's default sample type
+    sushi.py:769: index and float32 bits equal), both library paths agree."""
     from sushi_amd import synth
     from sushi_amd.device import SearchBatch
     from sushi_amd.wav import WavStream
     dst_pcm = synth.make_dst_pcm(seconds, rate, seed=seed)
     src_pcm = synth.make_src_pcm(dst_pcm, int(off_s * rate), seed=seed + 1)
-    dst = WavStream.from_samples(dst_pcm, rate, sample_rate=rate, sample_type="float32")
-    src = WavStream.from_samples(src_pcm, rate, sample_rate=rate, sample_type="float32")
+    dst = WavStream.from_samples(dst_pcm, rate, sample_rate=rate, sample_type=sample_type)
+    src = WavStream.from_samples(src_pcm, rate, sample_rate=rate, sample_type=sample_type)
     del dst_pcm, src_pcm
+    u8 = sample_type == "uint8"
     events = synth.make_events(n_events, seconds, window + off_s, seed=seed + 2, min_len=min_len, max_len=max_len)
     pats, centres, wins = synth.explicit_descriptors(src, dst, events, off_s, window, seed=seed + 3)
     diffs, times, positions = dst.find_substreams(pats, centres, wins, with_index=True)        # FFT path
@@ -507,8 +510,11 @@ def _planted_config(seconds, rate, window, n_events, off_s, seed, n_oracle, orac
     odst = oracle.OracleWavStream(dst.data, dst.sample_rate, dst.sample_count, dst.padding_size)
     for k in list(range(n_events))[:: max(1, n_events // n_oracle)][:n_oracle]:
         rdiff, rt = odst.find_substream(pats[k], centres[k], wins[k], matcher=oracle.match_template_fft)
-        assert abs(times[k] - rt) <= 1.0 / rate + 1e-12
-        assert _score_ok(diffs[k], rdiff), (diffs[k], rdiff)
+        if u8:
+            assert times[k] == rt and np.float32(diffs[k]).view(np.uint32) == np.float32(rdiff).view(np.uint32), (k, diffs[k], rdiff)
+        else:
+            assert abs(times[k] - rt) <= 1.0 / rate + 1e-12
+            assert _score_ok(diffs[k], rdiff), (diffs[k], rdiff)
     # the direct kernel on a couple of the same searches: same position, same float32 score
     sel = [0, n_events - 1]
     offs = [src._get_sample_for_time(events[k][0]) for k in sel]
@@ -522,19 +528,65 @@ def _planted_config(seconds, rate, window, n_events, off_s, seed, n_oracle, orac
     idx_d, score_d = b.results()
     for j, k in enumerate(sel):
         assert wst[j] + int(idx_d[j]) == positions[k]
-        assert abs(float(score_d[j]) - float(diffs[k])) <= 2.5e-7
+        assert abs(float(score_d[j]) - float(diffs[k])) <= (0.0 if u8 else 2.5e-7)
 
 
-def test_config3_sizes_two_hour_streams_120s_window(oracle):
+@pytest.mark.parametrize("sample_type", ["float32", "uint8"])
+def test_config3_sizes_two_hour_streams_120s_window(oracle, sample_type):
     """BASELINE configs[2] sizes: 2-h 12 kHz streams, +-120 s (P = 2,880,001); one rank's worth of events
-    is 375 -- 48 here, every one of them compared with the oracle (0.4 s of CPU each)."""
-    _planted_config(7200, 12000, 120, 48, 11.5, seed=31, n_oracle=48, oracle=oracle)
+    is 375 -- 48 here (float32; 24 for uint8), every one of them compared with the oracle (0.4 s of CPU each)."""
+    n = 48 if sample_type == "float32" else 24
+    _planted_config(7200, 12000, 120, n, 11.5, seed=31, n_oracle=n, oracle=oracle, sample_type=sample_type)
 
 
-def test_config5_sizes_24khz_four_hour_streams(oracle):
+@pytest.mark.parametrize("sample_type", ["float32", "uint8"])
+def test_config5_sizes_24khz_four_hour_streams(oracle, sample_type):
     """BASELINE configs[4] sizes: 4-h 24 kHz streams (346 M samples, 5.5 GB of block spectra), +-120 s
-    (P = 5,760,001), templates up to 5 s = 120,000 samples = 30 segments (two multiply-accumulate chunks)."""
-    _planted_config(14400, 24000, 120, 8, -17.25 + 40.0, seed=41, n_oracle=8, oracle=oracle, min_len=3.0, max_len=5.0)
+    (P = 5,760,001), templates up to 5 s = 120,000 samples = 30 segments (mac_long_kernel)."""
+    _planted_config(14400, 24000, 120, 8, -17.25 + 40.0, seed=41, n_oracle=8, oracle=oracle, min_len=3.0, max_len=5.0,
+                    sample_type=sample_type)
+
+
+@pytest.mark.parametrize("sample_type", ["float32", "uint8"])
+def test_config3_sizes_hard_material_through_the_tile_kernels(oracle, sample_type):
+    """BASELINE configs[2] sizes with what bench.py --hard-frac plants: a 2-h stream with digital silence, a held 400 Hz
+    tone and a recurring jingle every minute, +-120 s windows.  Events cut from there are tie-saturated (hundreds of
+    thousands of positions inside any margin: a +-120 s window holds four silences and four tones): they go through
+    collect_kernel + exact_tiles_kernel, and every one of them must give the oracle's FIRST index and its float32 score."""
+    from sushi_amd import synth
+    from sushi_amd.device import SearchBatch
+    from sushi_amd.wav import WavStream
+    rate, seconds, off, window = 12000, 7200.0, 7.25, 120.0
+    dst_pcm, spans = synth.make_hard_dst_pcm(seconds, rate, seed=91)
+    src_pcm = synth.make_src_pcm(dst_pcm, int(off * rate), seed=92)
+    dst = WavStream.from_samples(dst_pcm, rate, sample_rate=rate, sample_type=sample_type)
+    src = WavStream.from_samples(src_pcm, rate, sample_rate=rate, sample_type=sample_type)
+    del dst_pcm, src_pcm
+    events = synth.make_events(40, seconds, window + off, seed=93)
+    events, hard = synth.plant_hard_events(events, spans, off, 0.6, seed=94)
+    assert hard.sum() >= 24
+    pats, centres, wins = synth.explicit_descriptors(src, dst, events, off, window, seed=95)
+    offs = [src._get_sample_for_time(s) for s, _ in events]
+    lens = [p.shape[1] for p in pats]
+    wst, npos = [], []
+    for m, c, w in zip(lens, centres, wins):
+        _, lo, p = dst._window(m, c, w)
+        wst.append(lo); npos.append(p)
+    assert min(npos) >= 2_000_000
+    b = SearchBatch(dst.device_stream(), src.device_stream(), offs, lens, wst, npos, path="fft",
+                    workspace_bytes=64 << 30)
+    b.run()
+    idx, score = b.results()
+    d = b.diagnostics(per_search=True)
+    assert d["flagged"] >= 20 and d["all_positions"] == 0 and d["tiles_dense"] > 0 and d["tiles_sparse"] > 0
+    assert d["max_bound_ratio"] < 1.0
+    chk = _check_u8 if sample_type == "uint8" else _check_f32
+    for k in range(len(events)):
+        res = oracle.match_template_fft(dst.data[:, wst[k]:wst[k] + npos[k] + lens[k] - 1],
+                                        src.data[:, offs[k]:offs[k] + lens[k]])[0]
+        chk(res, idx[k], score[k])
+        if not hard[k]:
+            assert abs((wst[k] + int(idx[k])) - (offs[k] + int(off * rate))) <= 1
 
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.float32])

@@ -167,3 +167,40 @@ def test_format_time_reference_vectors():
     assert format_time(3600 + 60 * 15 + 35.15) == '1:15:35.15'
     assert format_time(544.997) == '0:09:05.00'
     assert format_time(0.005) == '0:00:00.01' and format_time(0.025) == '0:00:00.03'
+
+
+def test_truncated_and_placeholder_headers_do_not_size_buffers(tmp_path, monkeypatch):
+    """A data size that overstates the file (cut-off copy, 0xFFFFFFFF placeholder of a piped encoder): the raw-frame
+    buffers are sized by what the file holds; the frames that exist are decimated as the reference does (a short last
+    chunk by its own length, wav.py:127-134) and the part the reference leaves uninitialised (np.empty) is zero."""
+    import struct
+    from sushi_amd import synth
+    from sushi_amd.wav import DownmixedWavFile, WavStream
+    monkeypatch.setenv("SUSHI_HIP_LOAD", "host")
+    rate = 24000
+    pcm = synth.make_dst_pcm(3.5, rate, seed=3)
+    full = str(tmp_path / "full.wav")
+    synth.write_wav(full, pcm, rate)
+    blob = open(full, "rb").read()
+    cut = str(tmp_path / "cut.wav")
+    keep = 44 + 2 * int(2.3 * rate)
+    open(cut, "wb").write(blob[:keep])                               # header still says 3.5 s
+    w = DownmixedWavFile(cut)
+    assert w.frames_count == pcm.shape[0] and w.frames_available == int(2.3 * rate)
+    w.close()
+    s_cut = WavStream(cut, sample_rate=12000, sample_type="float32")
+    s_full = WavStream(full, sample_rate=12000, sample_type="float32")
+    assert s_cut.data.shape == s_full.data.shape and s_cut.sample_count == s_full.sample_count
+    # (the values are whatever wav.py:143-151 makes of a stream whose tail and right padding are zeros -- here the
+    # medians, and with them the scale, collapse exactly as they would in the reference)
+    # a placeholder size on a small file: nothing near 4 GiB of frames is allocated (this would take minutes / fail)
+    ph = str(tmp_path / "placeholder.wav")
+    open(ph, "wb").write(blob[:40] + struct.pack("<L", 0xFFFFFFFF) + blob[44:44 + 2 * rate])
+    w = DownmixedWavFile(ph)
+    assert w.frames_count == 0xFFFFFFFF // 2 and w.frames_available == rate
+    w.close()
+    # an empty data chunk: an error instead of arithmetic on uninitialised memory
+    empty = str(tmp_path / "empty.wav")
+    open(empty, "wb").write(blob[:40] + struct.pack("<L", 0))
+    with pytest.raises(SushiError):
+        WavStream(empty, sample_rate=12000, sample_type="float32")
