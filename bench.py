@@ -61,9 +61,20 @@ _cpu_ctx = {}
 
 
 def _cpu_init():
-    """Worker start: one thread per process (256 processes x an OpenMP team each is what made round 2's leg crawl)."""
+    """Worker start: one thread per process (256 processes x an OpenMP team each is what made round 2's leg crawl), and
+    a heap that keeps what it frees: every search allocates ~150 MB of NumPy temporaries, and 256 processes faulting
+    fresh pages in at once spend their time in the kernel's page allocator instead of the FFT (measured on the 256-core
+    box: 13.5 s per search against 0.076 s alone).  glibc serves blocks up to 32 MiB from the heap when told to."""
     from oracle import oracle as O
     O.set_num_threads(1)
+    try:
+        import ctypes
+        libc = ctypes.CDLL("libc.so.6")
+        libc.mallopt(-3, 32 << 20)         # M_MMAP_THRESHOLD: its maximum
+        libc.mallopt(-1, 1 << 30)          # M_TRIM_THRESHOLD: do not give the heap back between searches
+        libc.mallopt(-2, 64 << 20)         # M_TOP_PAD
+    except Exception:
+        pass
     try:
         from threadpoolctl import threadpool_limits
         _cpu_ctx["_tp"] = threadpool_limits(limits=1)
@@ -89,59 +100,83 @@ def _cpu_one(k):
     return idx, float(res[idx]), dt, real
 
 
-def oracle_leg(dst_row, src_row, offs, lens, wst, npos, method, forced, timed, min_sample=64, budget_s=12.0):
+def _spread(n):
+    """0 .. n-1 in an order whose every prefix is spread evenly over the range (bit reversal)."""
+    bits = max(1, int(n - 1).bit_length())
+    order = [int(format(i, "0%db" % bits)[::-1], 2) for i in range(1 << bits)]
+    return [i for i in order if i < n]
+
+
+def oracle_leg(dst_row, src_row, offs, lens, wst, npos, method, forced, timed, min_sample=64, budget_s=25.0, workers=None):
     """The CPU oracle over a sample of the workload, before CUDA is initialised (fork): the searches in `forced`, an
-    evenly spaced sample of at least `min_sample`, and -- `timed` -- as many more as ~budget_s of wall time per core
-    allows (at least 8 per worker), whose throughput is the cpu_baseline.  Returns (cpu_baseline | None, results)."""
+    evenly spread sample of at least `min_sample`, and -- `timed` -- as many more (evenly spread, at least 8 per worker)
+    as `budget_s` of wall time allows; their throughput is the cpu_baseline.  Returns (cpu_baseline | None, results)."""
     import multiprocessing as mp
     from oracle import oracle as O
     have_cv2 = O.cv2_module() is not None
     _cpu_ctx.update(dst=dst_row, src=src_row, offs=offs, lens=lens, wst=wst, npos=npos, method=method)
     n = len(offs)
     t0 = time.perf_counter()
-    _cpu_one(0)                         # imports, page-ins
+    cold = _cpu_one(0)                  # first call: imports, fresh pages
     first = _cpu_one(0)
     per_search = max(first[2], 1e-4)
     cores = max(1, os.cpu_count() or 1)
-    per_worker = int(min(32, max(8, budget_s / per_search)))
-    want = min(n, max(min_sample, cores * per_worker)) if timed else min(n, min_sample)
-    ks = sorted(set(np.linspace(0, n - 1, want).astype(int).tolist()) | set(int(k) for k in forced))
-    if have_cv2:                        # the real call on an evenly spaced part of the sample (bounded: it is slow too)
-        _cpu_ctx["cv2_set"] = set(ks[::max(1, len(ks) // 64)])
-    used = min(cores, len(ks))
-    results, wall = None, None
-    if used > 1:
-        try:
-            ctx = mp.get_context("fork")
-            with ctx.Pool(used, initializer=_cpu_init) as pool:
-                pool.map(_noop, range(used), chunksize=1)             # workers up before the clock starts
+    used = max(1, min(cores if workers is None else workers, n))
+    forced = [int(k) for k in forced]
+    rest = [k for k in _spread(n) if k not in set(forced)]
+    must = forced + rest[:max(0, min_sample - len(forced))]         # the parity sample: always
+    more = rest[max(0, min_sample - len(forced)):] if timed else []
+    if have_cv2:                        # the real call on an evenly spread part of the sample (bounded: it is slow too)
+        _cpu_ctx["cv2_set"] = set(must[:64])
+    results, wall, timed_n = {}, 0.0, 0
+    try:
+        if used < 2:
+            raise RuntimeError("single core")
+        ctx = mp.get_context("fork")
+        with ctx.Pool(used, initializer=_cpu_init) as pool:
+            pool.map(_noop, range(used), chunksize=1)             # workers up before the clock starts
+            # rounds of 8 searches per worker until the budget is spent: the first round(s) hold the parity sample
+            todo = must + more
+            pos = 0
+            while pos < len(todo):
+                batch = todo[pos:pos + 8 * used]
+                if pos >= len(must) and (wall > budget_s or not timed):
+                    break
                 t1 = time.perf_counter()
-                out = pool.map(_cpu_one, ks, chunksize=max(1, len(ks) // (used * 4)))
-                wall = time.perf_counter() - t1
-            results = {k: o for k, o in zip(ks, out)}
-        except Exception:
-            results, wall = None, None
-    if results is None:
+                out = pool.map(_cpu_one, batch, chunksize=max(1, len(batch) // (used * 2)))
+                dt = time.perf_counter() - t1
+                if len(batch) >= used:                            # rounds that fill every worker count for the rate
+                    wall += dt
+                    timed_n += len(batch)
+                results.update(zip(batch, out))
+                pos += len(batch)
+    except Exception:
         used = 1
-        if timed:
-            ks = ks[:max(min_sample, int(budget_s / per_search))]
+        todo = [k for k in must if k not in results]
         t1 = time.perf_counter()
-        results = {k: _cpu_one(k) for k in ks}
-        wall = time.perf_counter() - t1
+        for k in todo:
+            results[k] = _cpu_one(k)
+        if timed:
+            for k in more:
+                if time.perf_counter() - t1 > budget_s:
+                    break
+                results[k] = _cpu_one(k)
+        wall, timed_n = time.perf_counter() - t1, len(results)
     cpu = None
-    if timed:
-        value = len(results) / wall
+    if timed and timed_n and wall > 0:
+        value = timed_n / wall
         one_core = 1.0 / per_search
         busy = sum(r[2] for r in results.values())
         cpu = {"value": value, "unit": "events/s", "cores": used, "kind": "port",
-               "sample": "%d of the %d searches of this workload (evenly spaced%s), NumPy/SciPy float64 overlap-add FFT "
-                         "restatement of cv2.matchTemplate(%s), one single-threaded process per core, %d searches each"
-                         % (len(results), n, " + every tie-saturated one" if len(forced) else "",
-                            METHOD_TEXT[method].split(" ")[0], max(1, len(results) // used)),
+               "sample": "%d of the %d searches of this workload (evenly spread%s), NumPy/SciPy float64 overlap-add FFT "
+                         "restatement of cv2.matchTemplate(%s), one single-threaded process per core in rounds of 8 "
+                         "searches each, %.0f s budget" % (len(results), n, " + every tie-saturated one" if forced else "",
+                                                          METHOD_TEXT[method].split(" ")[0], budget_s),
                "value_1core": one_core, "parallel_efficiency": value / (used * one_core),
-               # what the workers themselves measured: sum of per-search seconds / (wall x workers) = how busy they were;
-               # mean per-search seconds under load vs alone = what 256 of them cost each other in memory bandwidth
-               "worker_busy_frac": busy / (wall * used), "per_search_s_alone": per_search,
+               # one search alone: the first call (fresh pages) and a repeat (warm heap); the same under load, as the
+               # workers timed themselves.  The gap between `alone` and `loaded` is what the processes cost each other
+               # (page faults of the NumPy temporaries, memory bandwidth), not arithmetic.
+               "per_search_s_alone_cold": cold[2], "per_search_s_alone": per_search,
                "per_search_s_loaded": busy / max(1, len(results)),
                "seconds": time.perf_counter() - t0}
     return cpu, results
@@ -200,6 +235,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the TIMING of the oracle (cpu_baseline: null); the parity sample is still run")
     ap.add_argument("--cpu-sample", type=int, default=64, help="searches of the workload the oracle is run on, at least")
+    ap.add_argument("--cpu-workers", type=int, default=None, help="processes of the oracle leg (default: one per host core)")
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--path", choices=("fft", "direct"), default="fft")
     ap.add_argument("--ws-mb", type=int, default=None, help="FFT path scratch per batch (MiB); default: what one "
@@ -287,7 +323,8 @@ def main():
     if rank == 0 and not dry:
         timed = world == 1 and not args.no_cpu_baseline
         cpu, cpu_results = oracle_leg(dst.data[0], src.data[0], offs, lens, wst, npos, args.method,
-                                      forced=np.nonzero(hard_mask)[0], timed=timed, min_sample=args.cpu_sample)
+                                      forced=np.nonzero(hard_mask)[0], timed=timed, min_sample=args.cpu_sample,
+                                      workers=args.cpu_workers)
 
     import torch
     import torch.distributed as dist

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SUSHI_HIP_ABI_VERSION 6
+#define SUSHI_HIP_ABI_VERSION 7
 
 #if defined(__GNUC__)
 #define SUSHI_HIP_API __attribute__((visibility("default")))
@@ -58,7 +58,7 @@ extern "C" {
 
 /* what cv2.matchTemplate's `method` argument selects (and which extremum the caller takes) */
 #define SUSHI_HIP_METHOD_SQDIFF_NORMED 0  /* cv2.TM_SQDIFF_NORMED + argmin: what wav.py:185-186 does; both paths */
-#define SUSHI_HIP_METHOD_CCOEFF_NORMED 1  /* cv2.TM_CCOEFF_NORMED + argmax (BASELINE.json's wording); direct path only */
+#define SUSHI_HIP_METHOD_CCOEFF_NORMED 1  /* cv2.TM_CCOEFF_NORMED + argmax (BASELINE.json's wording); both paths */
 
 SUSHI_HIP_API int sushi_hip_abi_version(void);
 SUSHI_HIP_API const char* sushi_hip_strerror(int code);
@@ -75,6 +75,7 @@ SUSHI_HIP_API int sushi_hip_device_ok(void);
  *              integral cv2 builds per call; exact for uint8)
  *   urel[n+1]  float32 + base[nb+1] float64, nb = ceil(n / B), B = sushi_hip_fft_block():
  *              s2[e] = base[e / B] + urel[e]   (the window energies in the cheap form the FFT scoring reads)
+ *   srel[n+1]  float32 + base1[nb+1] float64: the same for s1 (window sums of TM_CCOEFF_NORMED)
  *   spectra    (searchable streams only; sushi_hip_stream_add_spectra attaches them later)  for every block
  *              j = 0 .. nb-1 the N-point complex DFT, N = sushi_hip_fft_size(), H = N - B, of
  *                  x[jB .. jB+N) + i * x[jB+H .. jB+H+N)         (zeros past the end)
@@ -97,6 +98,8 @@ SUSHI_HIP_API int sushi_hip_stream_add_spectra(SushiHipStream* stream, void* mem
 #define SUSHI_HIP_VIEW_UREL 3
 #define SUSHI_HIP_VIEW_BASE 4
 #define SUSHI_HIP_VIEW_SPECTRA 5
+#define SUSHI_HIP_VIEW_SREL 6     /* float32[n+1]: s1[e] = base1[e / B] + srel[e] (TM_CCOEFF_NORMED's window sums on the FFT path) */
+#define SUSHI_HIP_VIEW_BASE1 7    /* float64[nb+1] */
 SUSHI_HIP_API int sushi_hip_stream_view(const SushiHipStream* stream, int which, const void** ptr_dev, size_t* bytes);
 SUSHI_HIP_API void sushi_hip_stream_destroy(SushiHipStream* stream);
 
@@ -133,7 +136,9 @@ typedef struct SushiHipBatchDiag {
     int64_t candidates;       /* listed candidate positions */
     float max_bound_ratio;    /* max over the exactly evaluated candidates of |f32 score - exact score| / the pair's
                                  modelled error bound (without the delta/2 floor); < 1 or the search went to all_positions */
-    float reserved;
+    float max_bound_ratio_noncandidate; /* the same over one pseudo-random NON-candidate position per search (the pair's
+                                 "audit" position, picked by a hash): the error model checked where it was not already
+                                 believed.  A violation there sends the search to all_positions too. */
 } SushiHipBatchDiag;
 
 typedef struct SushiHipBatch SushiHipBatch;
@@ -154,7 +159,7 @@ SUSHI_HIP_API int sushi_hip_batch_create(const SushiHipStream* dst, const SushiH
 SUSHI_HIP_API int sushi_hip_batch_info(const SushiHipBatch* batch, SushiHipBatchInfo* info);
 /* Matching method of the following runs (default after create: SUSHI_HIP_METHOD_SQDIFF_NORMED).
  * SUSHI_HIP_METHOD_CCOEFF_NORMED: out_idx = first index of the MAXIMUM of cv2.matchTemplate(..., TM_CCOEFF_NORMED),
- * out_score = that float32; EINVAL on an FFT-path batch. */
+ * out_score = that float32. */
 SUSHI_HIP_API int sushi_hip_batch_set_method(SushiHipBatch* batch, int method);
 /* One pass of the hot path over the batch (asynchronous):
  *   out_idx_dev[n]   = result.argmin(axis=1)[0]        (wav.py:186)

@@ -22,8 +22,8 @@ constexpr int FFT_HOP = FFT_SEG;                   // also the block size of the
 constexpr int FFT_VB = FFT_N / FFT_SEG - 1;        // valid blocks per half of a pair: 3
 constexpr int FFT_H = FFT_VB * FFT_SEG;            // result positions per half
 constexpr int FFT_STEP = 2 * FFT_VB;               // blocks between consecutive pairs
-constexpr int FFT_CAND = 8;                        // candidate slots per block pair (+ overflow marker + error bound)
-constexpr int FFT_ROW = FFT_CAND + 2;              // 64-bit entries per pair in the candidate array
+constexpr int FFT_CAND = 8;                        // candidate slots per block pair (+ overflow marker + error bound + audit position)
+constexpr int FFT_ROW = FFT_CAND + 3;              // 64-bit entries per pair in the candidate array
 constexpr int TILE = 1024;                         // positions per exact-evaluation tile (aligned to the absolute grid)
 constexpr int TILES_PER_PAIR = 2 * FFT_H / TILE;
 // error model of the f32 FFT stage: |corr_f32 - corr| <= FFT_KE * 2^-24 * |T| * |Z|, Z = the samples that enter the

@@ -318,20 +318,25 @@ void exact_tiles_kernel(TileParams a) {
             }
         }
         const TemplStats ts = templ_stats(a.r.src_s1, a.r.src_s2, sd.tmpl_off, M, a.r.centre);
+        const double* __restrict__ w1 = a.r.dst_s1 + sd.win_start;
         const double* __restrict__ w2 = a.r.dst_s2 + sd.win_start;
+        const bool ccoeff = a.method == SUSHI_HIP_METHOD_CCOEFF_NORMED;
+        auto key_at = [&](const double corr_u, const int p) {
+            return ccoeff ? make_key_max(finish_ccoeff_normed(corr_u, w1[p + M] - w1[p], w2[p + M] - w2[p], ts, M), (unsigned)p)
+                          : make_key(score_exact(corr_u, ts, w2, (int64_t)p, M), (unsigned)p);
+        };
         unsigned long long best = NO_KEY;
         if (dense) {
 #pragma unroll
             for (int q = 0; q < XQ; ++q) {
                 const int p = p0 + XQ * tid + q;
                 if (p >= 0 && p < sd.n_pos) {
-                    const unsigned long long key = make_key(score_exact(tot[q], ts, w2, (int64_t)p, M), (unsigned)p);
+                    const unsigned long long key = key_at(tot[q], p);
                     best = key < best ? key : best;
                 }
             }
         } else if (mine >= 0) {
-            const int p = p0 + mine;
-            best = make_key(score_exact(tot[0], ts, w2, (int64_t)p, M), (unsigned)p);
+            best = key_at(tot[0], p0 + mine);
         }
         best = wave_min_u64(best);
         if ((tid & 63) == 0) red[tid >> 6] = best;
@@ -364,10 +369,12 @@ __global__ void unpack_keys_kernel(const unsigned long long* __restrict__ keys, 
 // ------------------------------------------------------------------------------------------
 constexpr int RCAP = 128;
 
+// `n` listed entries; entry `audit_k` (or -1) is not a candidate but the pair's audit position with its plain f32 score:
+// it is evaluated like the others and only checked against the bound (the two-sided check of the error model).
 template <typename T>
 __device__ __forceinline__ void refine_body(const RefineParams& a, const int s_idx, const SearchDesc& sd,
                                             const unsigned long long* list, const int* lpair,
-                                            const unsigned long long* rows, const int n, double* part,
+                                            const unsigned long long* rows, const int n, const int audit_k, double* part,
                                             unsigned long long* rkey, float* rerr, int* violated) {
     const int tid = threadIdx.x;
     const int M = sd.tmpl_len;
@@ -375,18 +382,32 @@ __device__ __forceinline__ void refine_body(const RefineParams& a, const int s_i
     const T* __restrict__ Tp = (const T*)a.r.src_raw + sd.tmpl_off;
     const T* __restrict__ Wp = (const T*)a.r.dst_raw + sd.win_start;
     const TemplStats ts = templ_stats(a.r.src_s1, a.r.src_s2, sd.tmpl_off, M, a.r.centre);
+    const double* __restrict__ w1 = a.r.dst_s1 + sd.win_start;
     const double* __restrict__ w2 = a.r.dst_s2 + sd.win_start;
+    const bool ccoeff = a.method == SUSHI_HIP_METHOD_CCOEFF_NORMED;
     auto finish = [&](const int k, const double corr_u) {
         const unsigned p = key_pos(list[k]);
-        const float score = score_exact(corr_u, ts, w2, (int64_t)p, M);
-        rkey[k] = make_key(score, p);
+        float score, ranked;                                    // cv2's float32; what the ranking stage approximates
+        if (ccoeff) {
+            score = finish_ccoeff_normed(corr_u, w1[p + M] - w1[p], w2[p + M] - w2[p], ts, M);
+            ranked = 1.0f - score;                              // arg-max as an arg-min (ifft_kernel ranks 1 - score)
+            rkey[k] = make_key_max(score, p);
+        } else {
+            score = score_exact(corr_u, ts, w2, (int64_t)p, M);
+            ranked = score;
+            rkey[k] = make_key(score, p);
+        }
         const unsigned long long eb = rows[(size_t)lpair[k] * FFT_ROW + FFT_CAND + 1];
         const float e_pair = __uint_as_float((unsigned)(eb & 0xffffffffull));
         const float e_model = __uint_as_float((unsigned)(eb >> 32));
         const float lb = key_score(list[k]);
         float err = 0.f;
-        if (lb > 0.f) {                                         // the f32 score itself (a bound clamped at 0 lost it)
-            err = fabsf((lb + e_pair) - score);
+        if (k == audit_k) {                                     // a position that was NOT selected: its plain f32 score
+            err = fabsf(lb - ranked);
+            if (err > e_pair * 1.001f + 1e-7f) *violated = 1;   // the model failed where nobody was looking: every position
+            if (e_model > 0.f) atomicMax(&a.counters->max_ratio_audit_bits, __float_as_uint(err / e_model));
+        } else if (lb > 0.f) {                                  // the f32 score itself (a bound clamped at 0 lost it)
+            err = fabsf((lb + e_pair) - ranked);
             if (err > e_pair * 1.001f + 1e-7f) *violated = 1;
             if (e_model > 0.f) atomicMax(&a.counters->max_ratio_bits, __float_as_uint(err / e_model));
         }
@@ -432,9 +453,9 @@ __device__ __forceinline__ void refine_body(const RefineParams& a, const int s_i
 
 __global__ __launch_bounds__(256)
 void refine_kernel(RefineParams a) {
-    __shared__ unsigned long long list[RCAP], rkey[RCAP];
-    __shared__ int lpair[RCAP];
-    __shared__ float rerr[RCAP];
+    __shared__ unsigned long long list[RCAP + 1], rkey[RCAP + 1];
+    __shared__ int lpair[RCAP + 1];
+    __shared__ float rerr[RCAP + 1];
     __shared__ double part[256];
     __shared__ int cnt, ovf, violated;
     const int tid = threadIdx.x;
@@ -443,12 +464,13 @@ void refine_kernel(RefineParams a) {
     const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
     if (tid == 0) { cnt = 0; ovf = 0; violated = 0; }
     __syncthreads();
-    const float U = key_score(a.gkeys[s_idx]);
+    // none: TM_CCOEFF_NORMED with every window uncertain -- then every listed position is a candidate
+    const float U = a.gkeys[s_idx] == NO_KEY ? 4.0f : key_score(a.gkeys[s_idx]);
     const unsigned long long* __restrict__ rows = a.cand + (size_t)(sd.first_pair - a.sub_first_pair) * FFT_ROW;
     const int n_ent = lay.n_pairs * FFT_ROW;
     for (int e = tid; e < n_ent; e += 256) {
         const int slot = e % FFT_ROW;
-        if (slot == FFT_CAND + 1) continue;                                    // the pair's error bound, not a key
+        if (slot > FFT_CAND) continue;                                         // the pair's error bound / audit position, not candidates
         const unsigned long long key = rows[e];
         if (key != NO_KEY && key_score(key) <= U) {
             if (slot == FFT_CAND) {
@@ -461,9 +483,32 @@ void refine_kernel(RefineParams a) {
     }
     __syncthreads();
     const int n = cnt < RCAP ? cnt : RCAP;
+    if (a.method == SUSHI_HIP_METHOD_CCOEFF_NORMED) {
+        // a pattern without variance: cv2 returns a result of all ones, whose first arg-max is position 0
+        const TemplStats ts = templ_stats(a.r.src_s1, a.r.src_s2, sd.tmpl_off, sd.tmpl_len, a.r.centre);
+        if (ts.flat) {
+            if (tid == 0) { a.keys[s_idx] = make_key_max(1.0f, 0u); a.gkeys[s_idx] = 0ull; }
+            return;
+        }
+    }
     if (!ovf) {
-        if (a.r.dtype == SUSHI_HIP_F32) refine_body<float>(a, s_idx, sd, list, lpair, rows, n, part, rkey, rerr, &violated);
-        else refine_body<uint8_t>(a, s_idx, sd, list, lpair, rows, n, part, rkey, rerr, &violated);
+        // one position per search that is NOT a candidate, picked by a hash of the search index among the pairs' audit
+        // slots: evaluated exactly like the candidates and held to the same bound (the check of the error model where
+        // it was not already believed)
+        int n_all = n, audit_k = -1;
+        {
+            const unsigned h = (unsigned)s_idx * 2654435761u;
+            const int pa = (int)((h >> 8) % (unsigned)lay.n_pairs);
+            const unsigned long long key = rows[(size_t)pa * FFT_ROW + FFT_CAND + 2];
+            if (key != NO_KEY) {
+                audit_k = n;
+                n_all = n + 1;
+                if (tid == 0) { list[n] = key; lpair[n] = pa; }
+            }
+        }
+        __syncthreads();
+        if (a.r.dtype == SUSHI_HIP_F32) refine_body<float>(a, s_idx, sd, list, lpair, rows, n_all, audit_k, part, rkey, rerr, &violated);
+        else refine_body<uint8_t>(a, s_idx, sd, list, lpair, rows, n_all, audit_k, part, rkey, rerr, &violated);
         __syncthreads();
     }
     if (tid == 0) {
@@ -579,7 +624,7 @@ template <typename T>
 __global__ __launch_bounds__(PB_THREADS)
 void final_scan_kernel(const T* __restrict__ raw, int64_t n, const double* __restrict__ bs1,
                        const double* __restrict__ bs2, double* __restrict__ s1, double* __restrict__ s2,
-                       float* __restrict__ urel) {
+                       float* __restrict__ urel, float* __restrict__ srel) {
     // A thread scans PB_PER_THREAD consecutive samples, but global memory is touched a workgroup-wide row at a
     // time: samples come in and prefix values go out through a padded LDS tile (index + index / 16: the
     // 16-element runs of neighbouring threads start in different banks).
@@ -612,7 +657,7 @@ void final_scan_kernel(const T* __restrict__ raw, int64_t n, const double* __res
     const double o1 = bs1[blockIdx.x], o2 = bs2[blockIdx.x];             // block bases
     if (blockIdx.x == 0 && tid == 0) {
         s1[0] = 0.0; s2[0] = 0.0;
-        if (n % PB == 0) urel[n] = 0.f;                                  // sample n opens a block of its own: base2[n / PB] = total
+        if (n % PB == 0) { urel[n] = 0.f; srel[n] = 0.f; }               // sample n opens a block of its own: base[n / PB] = total
     }
     // s1[e + 1], s2[e + 1] (inclusive sums) and urel[e] (exclusive, relative to the block), one array at a time
     {
@@ -651,6 +696,19 @@ void final_scan_kernel(const T* __restrict__ raw, int64_t n, const double* __res
         const int i = k * PB_THREADS + tid;
         // e == n inside this block (n % PB != 0): samples past the end are zeros, so the running sum there is the total
         if (blk + i <= n) urel[blk + i] = ftile[pad(i)];
+    }
+    // the same for the sum of the samples (TM_CCOEFF_NORMED's window means): s1[e] = base1[e / PB] + srel[e]
+    __syncthreads();
+    {
+        double r = e1;
+#pragma unroll
+        for (int k = 0; k < PB_PER_THREAD; ++k) { ftile[pad(tid * PB_PER_THREAD + k)] = (float)r; r += v[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PB_PER_THREAD; ++k) {
+        const int i = k * PB_THREADS + tid;
+        if (blk + i <= n) srel[blk + i] = ftile[pad(i)];
     }
 }
 
@@ -719,7 +777,7 @@ namespace {
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // where the parts of a prepared stream go inside the caller's buffer
-struct StreamLayout { size_t xc, s1, s2, urel, base, base_bytes, spec, total; };
+struct StreamLayout { size_t xc, s1, s2, urel, srel, base, base_bytes, spec, total; };
 
 StreamLayout stream_layout(int64_t n, int searchable) {
     StreamLayout l;
@@ -729,7 +787,8 @@ StreamLayout stream_layout(int64_t n, int searchable) {
     l.s1 = o; o += align_up((size_t)(n + 1) * sizeof(double), 256);
     l.s2 = o; o += align_up((size_t)(n + 1) * sizeof(double), 256);
     l.urel = o; o += align_up((size_t)(n + 1) * sizeof(float), 256);
-    l.base_bytes = (size_t)(2 * (nb + 1)) * sizeof(double);      // block bases of sum x^2, then (scratch) of sum x
+    l.srel = o; o += align_up((size_t)(n + 1) * sizeof(float), 256);
+    l.base_bytes = (size_t)(2 * (nb + 1)) * sizeof(double);      // block bases of sum x^2, then of sum x
     l.base = o; o += align_up(l.base_bytes, 256);
     l.spec = o; o += searchable ? align_up(sushi_hip_stream_spectra_bytes(n), 256) : 0;
     l.total = o;
@@ -788,7 +847,7 @@ int sushi_hip_stream_create(const void* raw_dev, int dtype, int64_t n, int searc
     char* m = (char*)mem_dev;
     s->raw = raw_dev; s->dtype = dtype; s->n = n;
     s->xc = (float*)(m + l.xc); s->s1 = (double*)(m + l.s1); s->s2 = (double*)(m + l.s2);
-    s->urel = (float*)(m + l.urel); s->base = (double*)(m + l.base); s->base_bytes = l.base_bytes;
+    s->urel = (float*)(m + l.urel); s->srel = (float*)(m + l.srel); s->base = (double*)(m + l.base); s->base_bytes = l.base_bytes;
     s->spec = nullptr; s->spec_bytes = 0; s->blocks = nb;
     hipStream_t st = (hipStream_t)hip_stream;
     double* bs2 = s->base;                       // block bases of sum x^2 (what the FFT path's scoring reads)
@@ -807,10 +866,10 @@ int sushi_hip_stream_create(const void* raw_dev, int dtype, int64_t n, int searc
     if (rc == SUSHI_HIP_OK) {
         if (dtype == SUSHI_HIP_F32)
             hipLaunchKernelGGL(final_scan_kernel<float>, dim3(nb), dim3(PB_THREADS), 0, st, (const float*)raw_dev, n,
-                               (const double*)bs1, (const double*)bs2, s->s1, s->s2, s->urel);
+                               (const double*)bs1, (const double*)bs2, s->s1, s->s2, s->urel, s->srel);
         else
             hipLaunchKernelGGL(final_scan_kernel<uint8_t>, dim3(nb), dim3(PB_THREADS), 0, st, (const uint8_t*)raw_dev, n,
-                               (const double*)bs1, (const double*)bs2, s->s1, s->s2, s->urel);
+                               (const double*)bs1, (const double*)bs2, s->s1, s->s2, s->urel, s->srel);
         rc = launch_ok();
     }
     if (rc == SUSHI_HIP_OK && searchable)
@@ -829,6 +888,8 @@ int sushi_hip_stream_view(const SushiHipStream* s, int which, const void** ptr_d
         case SUSHI_HIP_VIEW_UREL: *ptr_dev = s->urel; *bytes = (size_t)(s->n + 1) * sizeof(float); break;
         case SUSHI_HIP_VIEW_BASE: *ptr_dev = s->base; *bytes = (size_t)(s->blocks + 1) * sizeof(double); break;
         case SUSHI_HIP_VIEW_SPECTRA: *ptr_dev = s->spec; *bytes = s->spec_bytes; break;
+        case SUSHI_HIP_VIEW_SREL: *ptr_dev = s->srel; *bytes = (size_t)(s->n + 1) * sizeof(float); break;
+        case SUSHI_HIP_VIEW_BASE1: *ptr_dev = s->base + (s->blocks + 1); *bytes = (size_t)(s->blocks + 1) * sizeof(double); break;
         default: return SUSHI_HIP_EINVAL;
     }
     return SUSHI_HIP_OK;

@@ -17,7 +17,8 @@ struct SushiHipStream {
     double* s1;               // [n + 1]  prefix sums of the samples
     double* s2;               // [n + 1]  prefix sums of their squares
     float* urel;              // [n + 1]  s2 relative to the block base
-    double* base;             // [nb + 1] block bases of s2 (+ scratch behind it)
+    float* srel;              // [n + 1]  s1 relative to the block base (TM_CCOEFF_NORMED on the FFT path)
+    double* base;             // [nb + 1] block bases of s2, then [nb + 1] block bases of s1
     size_t base_bytes;
     void* spec;               // [(nb + 1) * N] complex f32 block spectra, or null
     size_t spec_bytes;
@@ -62,7 +63,7 @@ struct RunCounters {
     int32_t n_cand;           // entries of the candidate buffer (reset per sub-batch)
     unsigned long long tiles_dense, tiles_sparse, candidates;    // totals of the run
     uint32_t max_ratio_bits;  // float bits of SushiHipBatchDiag.max_bound_ratio
-    uint32_t pad;
+    uint32_t max_ratio_audit_bits;  // float bits of SushiHipBatchDiag.max_bound_ratio_noncandidate
 };
 
 int direct_variant_count();
@@ -87,6 +88,7 @@ struct RefineParams {
     int* sub_flagged;                 // [1] how many
     RunCounters* counters;
     float delta;
+    int method;                       // SUSHI_HIP_METHOD_*
 };
 int launch_refine(const RefineParams& p, hipStream_t st);
 
@@ -97,6 +99,7 @@ struct TileParams {
     const int32_t* cand;              // candidate positions (relative to the search window)
     unsigned long long* keys;
     RunCounters* counters;            // n_tiles read on the device
+    int method;                       // SUSHI_HIP_METHOD_*
 };
 int launch_tiles(const TileParams& p, hipStream_t st);
 int launch_unpack(const unsigned long long* keys_dev, int n, int method, int32_t* out_idx_dev, float* out_score_dev,

@@ -119,6 +119,8 @@ class DeviceStream(object):
     s1 = property(lambda self: self._view(_native.VIEW_S1, torch.float64))
     s2 = property(lambda self: self._view(_native.VIEW_S2, torch.float64))
     urel = property(lambda self: self._view(_native.VIEW_UREL, torch.float32))
+    srel = property(lambda self: self._view(_native.VIEW_SREL, torch.float32))
+    base1 = property(lambda self: self._view(_native.VIEW_BASE1, torch.float64))
     base = property(lambda self: self._view(_native.VIEW_BASE, torch.float64))
 
     def spectra(self):
@@ -153,7 +155,7 @@ class SearchBatch(object):
     Same results either way.
 
     method = 'sqdiff_normed' (default; cv2.TM_SQDIFF_NORMED + argmin, what wav.py:185-186 does) or 'ccoeff_normed'
-    (cv2.TM_CCOEFF_NORMED + argmax, the method BASELINE.json's wording names; direct path only).
+    (cv2.TM_CCOEFF_NORMED + argmax, the method BASELINE.json's wording names); both on either path.
     """
 
     def __init__(self, dst, src, tmpl_off, tmpl_len, win_start, n_pos, variant=None, path=None,
@@ -188,8 +190,6 @@ class SearchBatch(object):
         self.path = default_path() if path is None else path
         if self.path not in ("fft", "direct"):
             raise SushiError("path must be 'fft' or 'direct'")
-        if method != "sqdiff_normed" and self.path != "direct":
-            raise SushiError("method %r needs path='direct'" % method)
         path_code = _native.PATH_FFT if self.path == "fft" else _native.PATH_DIRECT
         req = np.zeros(n, dtype=_native.REQUEST_DTYPE)
         req["tmpl_off"], req["win_start"], req["tmpl_len"], req["n_pos"] = tmpl_off, win_start, tmpl_len, n_pos

@@ -342,7 +342,7 @@ class WavStream(object):
         Returns (diffs: float32 ndarray, times: list of float); with_index=True appends the absolute
         sample index of every match in self.data (what SpeculativeStream caches).
         method: 'sqdiff_normed' = what the reference's find_substream computes (wav.py:185-186: TM_SQDIFF_NORMED, argmin);
-        'ccoeff_normed' = cv2.TM_CCOEFF_NORMED with argmax instead (not used by the reference; direct kernel)."""
+        'ccoeff_normed' = cv2.TM_CCOEFF_NORMED with argmax instead (not used by the reference; the method BASELINE.json names)."""
         from .device import DeviceStream, SearchBatch
         n = len(patterns)
         if not (len(window_centers) == len(window_sizes) == n) or n == 0:
@@ -375,10 +375,7 @@ class WavStream(object):
             start_times.append(st)
             win_start.append(lo)
             n_pos.append(p)
-        if method == "sqdiff_normed":
-            batch = SearchBatch(dst_dev, src_dev, offs, lens, win_start, n_pos)
-        else:
-            batch = SearchBatch(dst_dev, src_dev, offs, lens, win_start, n_pos, path="direct", method=method)
+        batch = SearchBatch(dst_dev, src_dev, offs, lens, win_start, n_pos, method=method)
         batch.run()
         idx, score = batch.results()
         times = [st + (int(k) / float(self.sample_rate)) for st, k in zip(start_times, idx)]

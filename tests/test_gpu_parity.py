@@ -562,9 +562,9 @@ def test_config3_sizes_hard_material_through_the_tile_kernels(oracle, sample_typ
     dst = WavStream.from_samples(dst_pcm, rate, sample_rate=rate, sample_type=sample_type)
     src = WavStream.from_samples(src_pcm, rate, sample_rate=rate, sample_type=sample_type)
     del dst_pcm, src_pcm
-    events = synth.make_events(40, seconds, window + off, seed=93)
+    events = synth.make_events(72, seconds, window + off, seed=93)
     events, hard = synth.plant_hard_events(events, spans, off, 0.6, seed=94)
-    assert hard.sum() >= 24
+    assert hard.sum() >= 40                                   # silence and tone events are tie-saturated, jingles are not
     pats, centres, wins = synth.explicit_descriptors(src, dst, events, off, window, seed=95)
     offs = [src._get_sample_for_time(s) for s, _ in events]
     lens = [p.shape[1] for p in pats]
@@ -579,7 +579,7 @@ def test_config3_sizes_hard_material_through_the_tile_kernels(oracle, sample_typ
     idx, score = b.results()
     d = b.diagnostics(per_search=True)
     assert d["flagged"] >= 20 and d["all_positions"] == 0 and d["tiles_dense"] > 0 and d["tiles_sparse"] > 0
-    assert d["max_bound_ratio"] < 1.0
+    assert d["max_bound_ratio"] < 1.0 and d["max_bound_ratio_noncandidate"] < 1.0
     chk = _check_u8 if sample_type == "uint8" else _check_f32
     for k in range(len(events)):
         res = oracle.match_template_fft(dst.data[:, wst[k]:wst[k] + npos[k] + lens[k] - 1],
@@ -606,6 +606,7 @@ def test_fft_streams_far_from_the_centring_constant(oracle, dtype):
     assert b.fallback_count() == 0
     assert b.ranking_errors().max() < b.delta / 4
     assert b.diagnostics()["max_bound_ratio"] < 0.5        # measured f32 error against the modelled bound
+    assert b.diagnostics()["max_bound_ratio_noncandidate"] < 0.5   # the same at positions that were not candidates
     for k, (m, w, p) in enumerate([(5000, 1000, 50001), (2500, 20000, 20001)]):
         res = oracle.match_template(dst[w:w + p + m - 1], src[:m])[0]
         (_check_u8 if dtype == np.uint8 else _check_f32)(res, idx[k], score[k])
@@ -635,6 +636,8 @@ def test_fft_ranking_error_is_far_below_delta():
         err = b.ranking_errors()
         assert b.fallback_count() == 0
         assert err.max() < b.delta / 8, err.max()
+        dg = b.diagnostics()
+        assert 0.0 < dg["max_bound_ratio_noncandidate"] < 0.5      # 64 audited non-candidate positions, all far inside the bound
 
 
 @pytest.mark.parametrize("variant", [2, "fft"])
@@ -726,7 +729,8 @@ def test_quiet_passage_inside_a_loud_block_matches_oracle(oracle):
         assert best_p == int(idx[k])
         assert abs(float(score[k]) - best) <= 2e-3 * best + 2.5e-7, (score[k], best)
     assert idx[0] == 69000 and idx[1] == 45000
-    assert d["max_bound_ratio"] < 1.0                    # every evaluated candidate was inside its modelled bound
+    assert d["max_bound_ratio"] < 1.0                    # every evaluated candidate was inside its modelled bound ...
+    assert d["max_bound_ratio_noncandidate"] < 1.0       # ... and so was one position per search that was NOT a candidate
     assert d["all_positions"] == 0
 
 
