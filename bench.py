@@ -100,6 +100,35 @@ def _cpu_one(k):
     return idx, float(res[idx]), dt, real
 
 
+def usable_cores():
+    """Host cores this process can actually use: the affinity mask and the cgroup CPU quota, not os.cpu_count() (the GPU
+    boxes report 256 logical CPUs and grant a container about three of them: 256 workers then time-share those)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                    # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n), quota
+
+
 def _spread(n):
     """0 .. n-1 in an order whose every prefix is spread evenly over the range (bit reversal)."""
     bits = max(1, int(n - 1).bit_length())
@@ -120,7 +149,7 @@ def oracle_leg(dst_row, src_row, offs, lens, wst, npos, method, forced, timed, m
     cold = _cpu_one(0)                  # first call: imports, fresh pages
     first = _cpu_one(0)
     per_search = max(first[2], 1e-4)
-    cores = max(1, os.cpu_count() or 1)
+    cores, quota = usable_cores()
     used = max(1, min(cores if workers is None else workers, n))
     forced = [int(k) for k in forced]
     rest = [k for k in _spread(n) if k not in set(forced)]
@@ -167,7 +196,8 @@ def oracle_leg(dst_row, src_row, offs, lens, wst, npos, method, forced, timed, m
         value = timed_n / wall
         one_core = 1.0 / per_search
         busy = sum(r[2] for r in results.values())
-        cpu = {"value": value, "unit": "events/s", "cores": used, "kind": "port",
+        cpu = {"value": value, "unit": "events/s", "cores": used, "logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota,
+               "kind": "port",
                "sample": "%d of the %d searches of this workload (evenly spread%s), NumPy/SciPy float64 overlap-add FFT "
                          "restatement of cv2.matchTemplate(%s), one single-threaded process per core in rounds of 8 "
                          "searches each, %.0f s budget" % (len(results), n, " + every tie-saturated one" if forced else "",

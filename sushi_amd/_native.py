@@ -80,6 +80,8 @@ def lib():
     L.sushi_hip_device_ok.restype = ci
     L.sushi_hip_fft_size.restype = ci
     L.sushi_hip_fft_block.restype = ci
+    L.sushi_hip_fft_slot_of_bin.restype = ci
+    L.sushi_hip_fft_slot_of_bin.argtypes = [ci]
     L.sushi_hip_centre.restype = dbl
     L.sushi_hip_centre.argtypes = [ci]
     L.sushi_hip_stream_bytes.restype = sz

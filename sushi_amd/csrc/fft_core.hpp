@@ -35,8 +35,10 @@
 
 #ifdef __HIPCC__
 #define SUSHI_HD __device__ __forceinline__
+#define SUSHI_HHD __host__ __device__ inline
 #else
 #define SUSHI_HD inline
+#define SUSHI_HHD inline
 #endif
 
 namespace sushi_fft {
@@ -197,6 +199,138 @@ SUSHI_HD void split_load(cpx* v, int tid, const float* lds) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Wave plan for 16384 points (the INVERSE transforms of ifft_kernel / collect_kernel): 16 x 16 x 4 x 16, where the
+// first three passes stay inside a wave and only the last exchange crosses the workgroup.
+//
+// Why: LDS traffic and VALU work of a CU hardly overlap on gfx950 (tools/ubench/valu_lds_overlap.hip: 16 dwords per lane
+// out and back cost 87 cycles per wave as b32 operations, 59 as b64, and a wave's FMAs next to them only partly hide);
+// the 8 x 8 x 16 x 16 plan above moves every point through the LDS three times as single dwords and takes 11 barriers.
+// This plan moves every point through the LDS twice, reads it back as 8-byte pairs, and takes 4 barriers:
+//
+//   index split   n = n1 + 16 n2 (n1 = wave),  n2 = 64 d1 + 4 d2 + d3   (d1: registers, d2 = lane & 15, d3 = lane >> 4)
+//   pass 1        16-point DFTs over d1 -> e1                               in registers
+//   row exchange  (lane & 15, register) transposed inside every row of 16 lanes, through the wave's OWN 1152 floats of
+//                 the buffer (no barrier: a wave's LDS operations execute in order); rows padded to 18 floats so that the
+//                 b32 stores are 2-way (free) and the b64 loads conflict-free
+//   pass 2        twiddle w256^(e1 d2), 16-point DFTs over d2 -> e2         in registers
+//   swap          register bits 3:2 <-> lane bits 5:4 with v_permlane32_swap / v_permlane16_swap (no LDS)
+//   pass 3        twiddle w1024^(d3 (e1 + 16 e2)), 4-point DFTs over d3 -> e3
+//                 the wave now holds A_n1[k2] = sum_n2 x[n1 + 16 n2] w1024^(n2 k2),  k2 = e1 + 16 e2 + 256 e3
+//   wg exchange   to thread k2 = tid, register n1: position 18 k2 + n1 (2-way stores, conflict-free b64 loads)
+//   pass 4        twiddle w16384^(n1 k2), 16-point DFTs over n1 -> k1:  thread tid ends with X[tid + 1024 k1]
+//
+// The input order is whatever makes the first loads coalesced: thread (wave w, lane l) register d1 holds
+// x[w + 1024 d1 + 64 (l & 15) + 16 (l >> 4)], and the spectra this transform consumes are STORED in that order
+// (`wslot`: mac_kernel only needs rows, pattern spectra and products to agree on one order of the bins).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int WN = 16384, WNT = 1024;
+constexpr int WROW = 18;                       // floats per padded run of 16
+constexpr int W_LDS_FLOATS = WROW * 1024;      // 72 KB: the workgroup exchange; a wave's row exchange uses floats [1152 w, 1152 w + 1152)
+
+// float4 index, inside a stored spectrum of N complex values, of the register pair (2t, 2t+1) of thread `tid`
+SUSHI_HD int wslot_float4(int tid, int t) { return (((tid >> 6) * 8 + t) << 6) + (tid & 63); }
+// the frequency bin a thread's register d1 holds when it loads a stored spectrum
+SUSHI_HD int wbin(int tid, int d1) { return (tid >> 6) + 1024 * d1 + 64 * (tid & 15) + 16 * ((tid >> 4) & 3); }
+// complex index, inside a stored spectrum, of bin f
+SUSHI_HHD int wslot_of_bin(int f) {
+    const int w = f & 15, d3 = (f >> 4) & 3, d2 = (f >> 6) & 15, d1 = f >> 10;
+    return ((((w * 8 + (d1 >> 1)) << 6) + 16 * d3 + d2) << 1) + (d1 & 1);
+}
+
+struct WTwiddles { cpx g2, q3, p4; };
+
+template <int DIR>
+SUSHI_HD WTwiddles load_wtwiddles(int tid, const cpx* __restrict__ tw) {
+    WTwiddles t;
+    const int lane = tid & 63;
+    t.g2 = tw[(lane & 15) * (TWIDDLE_N / 256)];                          // pass 2: w256^(e1), e1 = lane & 15 after the row exchange
+    t.q3 = tw[((lane & 15) + 64 * (lane >> 4)) * (TWIDDLE_N / 1024)];    // pass 3: w1024^(e1 + 64 e2hi), e2hi = lane >> 4 after the swap
+    t.p4 = tw[tid * (TWIDDLE_N / WN)];                                   // pass 4: w16384^(k2), k2 = tid
+    if (DIR > 0) { t.g2 = cconj(t.g2); t.q3 = cconj(t.q3); t.p4 = cconj(t.p4); }
+    return t;
+}
+
+// row exchange: element (row, c = lane & 15, register q) -> (row, c' = q, register c)
+template <int IM>
+SUSHI_HD void w_row_store(const cpx* v, int tid, float* lds) {
+    float* out = lds + (tid >> 6) * (64 * WROW) + ((tid >> 4) & 3) * (16 * WROW) + (tid & 15);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) out[WROW * q] = part_of<IM>(v[q]);
+}
+template <int IM>
+SUSHI_HD void w_row_load(cpx* v, int tid, const float* lds) {
+    const float* in = lds + (tid >> 6) * (64 * WROW) + ((tid >> 4) & 3) * (16 * WROW) + WROW * (tid & 15);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                                         // 8-byte aligned pairs
+        // (volatile: two plain 8-byte loads next to each other are merged into ds_read2_b64, which runs at half the
+        // rate of ds_read_b64; the positions are only 8-byte aligned, so ds_read_b128 is not available)
+        struct f2 { float a, b; };
+#ifdef __HIPCC__
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        typedef const volatile __attribute__((address_space(3))) f2v* lds_f2v;    // (a volatile access through a generic pointer is a flat load)
+        const f2v pv = *(lds_f2v)(in + 2 * i);
+        const f2 p = {pv.x, pv.y};
+#else
+        const f2 p = {in[2 * i], in[2 * i + 1]};
+#endif
+        set_part<IM>(v[2 * i], p.a);
+        set_part<IM>(v[2 * i + 1], p.b);
+    }
+}
+
+// pass 3 after the swap: register 4 d3 + e2lo.  Twiddle (q3 * w64^e2lo)^d3, then 4-point DFTs over d3.
+template <int DIR>
+SUSHI_HD void w_pass3(cpx* v, const cpx q3) {
+    const float s = (float)DIR;
+    // exp(DIR 2 pi i e / 64), e = 1, 2, 3
+    const cpx w64[4] = {cpx{1.f, 0.f}, cpx{0.99518472667219688624f, s * 0.09801714032956060199f},
+                        cpx{0.98078528040323044913f, s * 0.19509032201612826785f},
+                        cpx{0.95694033573220886494f, s * 0.29028467725446236764f}};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const cpx z = e == 0 ? q3 : cmul(q3, w64[e]);
+        const cpx z2 = cmul(z, z);
+        const cpx z3 = cmul(z2, z);
+        v[4 + e] = cmul(v[4 + e], z);
+        v[8 + e] = cmul(v[8 + e], z2);
+        v[12 + e] = cmul(v[12 + e], z3);
+        cpx b[4] = {v[e], v[4 + e], v[8 + e], v[12 + e]};
+        Dft<4, DIR>::run(b);
+        v[e] = b[0]; v[4 + e] = b[1]; v[8 + e] = b[2]; v[12 + e] = b[3];
+    }
+}
+
+// workgroup exchange: wave n1 holds A_n1[k2] at register 4 e3 + e2lo of lane (e2hi = lane >> 4, e1 = lane & 15),
+// k2 = e1 + 64 e2hi + 16 e2lo + 256 e3; it goes to position 18 k2 + n1, thread k2 reads its 16 values back as pairs
+template <int IM>
+SUSHI_HD void w_wg_store(const cpx* v, int tid, float* lds) {
+    const int lane = tid & 63;
+    float* out = lds + WROW * ((lane & 15) + 64 * (lane >> 4)) + (tid >> 6);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[WROW * (16 * (r & 3) + 256 * (r >> 2))] = part_of<IM>(v[r]);
+}
+template <int IM>
+SUSHI_HD void w_wg_load(cpx* v, int tid, const float* lds) {
+    const float* in = lds + WROW * tid;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        // (volatile: two plain 8-byte loads next to each other are merged into ds_read2_b64, which runs at half the
+        // rate of ds_read_b64; the positions are only 8-byte aligned, so ds_read_b128 is not available)
+        struct f2 { float a, b; };
+#ifdef __HIPCC__
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        typedef const volatile __attribute__((address_space(3))) f2v* lds_f2v;    // (a volatile access through a generic pointer is a flat load)
+        const f2v pv = *(lds_f2v)(in + 2 * i);
+        const f2 p = {pv.x, pv.y};
+#else
+        const f2 p = {in[2 * i], in[2 * i + 1]};
+#endif
+        set_part<IM>(v[2 * i], p.a);
+        set_part<IM>(v[2 * i + 1], p.b);
+    }
+}
+
 #ifdef __HIPCC__
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
@@ -228,6 +362,45 @@ __device__ __forceinline__ void fft_split(cpx* v, int tid, float* lds, const Twi
     __syncthreads();
     exchange_split<LOGN, 3>(v, tid, lds, before_last_pass);
     pass_compute<R4, P::NT, DIR>(v, tw.p4);
+}
+// The wave plan's transform of the 16 points in v (register d1 of thread (w, l) = x[wbin(tid, d1)]) -> v[k1] = X[tid + 1024 k1].
+// `lds`: W_LDS_FLOATS floats, dead after the call (reusable after one further __syncthreads()).
+template <int DIR>
+__device__ __forceinline__ void fft_wave(cpx* v, int tid, float* lds, const WTwiddles tw) {
+    Dft<16, DIR>::run(v);                                        // pass 1
+    // row exchange inside the wave: its LDS operations execute in order, nobody else touches its 1152 floats
+    w_row_store<0>(v, tid, lds);
+    __builtin_amdgcn_wave_barrier();
+    w_row_load<0>(v, tid, lds);
+    __builtin_amdgcn_wave_barrier();
+    w_row_store<1>(v, tid, lds);
+    __builtin_amdgcn_wave_barrier();
+    w_row_load<1>(v, tid, lds);
+    pass_compute<16, 16, DIR>(v, tw.g2);                         // pass 2 (twiddle, then the DFTs)
+    // register bits 3:2 <-> lane bits 5:4
+    auto swap32 = [](float& a, float& b) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+    };
+    auto swap16 = [](float& a, float& b) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+    };
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { swap32(v[r].x, v[r + 8].x); swap32(v[r].y, v[r + 8].y); }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if ((r & 4) == 0) { swap16(v[r].x, v[r + 4].x); swap16(v[r].y, v[r + 4].y); }
+    w_pass3<DIR>(v, tw.q3);                                      // pass 3
+    __syncthreads();                                             // every wave is done with its row-exchange floats
+    w_wg_store<0>(v, tid, lds);
+    __syncthreads();
+    w_wg_load<0>(v, tid, lds);
+    __syncthreads();
+    w_wg_store<1>(v, tid, lds);
+    __syncthreads();
+    w_wg_load<1>(v, tid, lds);
+    pass_compute<16, WNT, DIR>(v, tw.p4);                        // pass 4
 }
 #endif  // __HIPCC__
 

