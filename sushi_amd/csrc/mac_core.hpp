@@ -58,7 +58,7 @@ SUSHI_MAC_HD void group_range(long long pair_lo, long long pair_hi, long long* j
 // into a store to a dummy line instead of branching around it, so that the number of memory operations per group is
 // a compile-time constant (with a conditional store in the loop the compiler cannot count what is in flight and drains
 // every outstanding load at every group).
-template <int SMAX, int STEP, class GetZ, class Store>
+template <int SMAX, int STEP, int ZP = 3, class GetZ, class Store>
 SUSHI_MAC_HD void mac_group(const long long jb, const long long pair_lo, const long long pair_hi,
                             const c2 (&tt)[SMAX], c2 (&acc)[SMAX / STEP], GetZ& get_z, Store& store) {
     static_assert(SMAX % STEP == 0 && SMAX >= STEP, "SMAX must be a multiple of STEP");
@@ -66,7 +66,6 @@ SUSHI_MAC_HD void mac_group(const long long jb, const long long pair_lo, const l
     const long long ib = jb / STEP;                                    // jb is a multiple of SMAX, hence of STEP
     // rows are requested two steps before their use (get_z is an LDS read on the device: its latency then hides
     // behind the multiply-accumulates of two rows instead of being waited for at every row)
-    constexpr int ZP = 3;
     c2 zq[ZP];
 #pragma unroll
     for (int u = 0; u < ZP - 1 && u < SMAX; ++u) zq[u] = get_z(u);

@@ -204,10 +204,11 @@ __host__ __device__ inline FftLayout fft_layout(int64_t win_start, int n_pos, in
 }
 
 // segment-count class of a search: the smallest SMAX (a multiple of FFT_STEP) that holds the whole pattern.  Classes
-// 0 .. MAC_SHORT_CLASSES-1 (up to 18 segments) run in mac_kernel, the others (up to 36) in mac_long_kernel, which keeps
-// twice the pattern spectra per lane at a lower occupancy; still longer patterns use the largest class and several
-// chunks of its SMAX segments, the output accumulating.
-constexpr int MAC_CLASSES = 6;
+// 0 .. MAC_SHORT_CLASSES-1 (up to 18 segments) run in mac_kernel, the others (up to 30: a 5 s pattern at 24 kHz, BASELINE
+// configs[4]'s longest) in mac_long_kernel, which keeps more pattern spectra per lane at a lower occupancy; still longer
+// patterns use the largest class and several chunks of its SMAX segments, the output accumulating.  (A sixth class of 36
+// segments made mac_long_kernel spill at its 256 registers: 144 of them were pattern spectra.)
+constexpr int MAC_CLASSES = 5;
 constexpr int MAC_SHORT_CLASSES = 3;
 __host__ __device__ constexpr int mac_class_smax(int c) { return FFT_STEP * (c + 1); }
 __host__ __device__ inline int mac_class(int n_seg) {

@@ -66,10 +66,30 @@ static_assert(FFT_LOGN == 14 && sushi_fft::W_LDS_FLOATS <= LDS_FLOATS && FT == s
 
 // Spectra are STORED in the order the inverse transform loads them (fft_core.hpp "Wave plan": wslot_of_bin): block
 // spectra, pattern spectra and their products only have to agree on one order of the bins.  A forward transform ends with
-// thread tid holding X[tid + 1024 r] in register r; registers (2t, 2t+1) go out as one float4.
-__device__ __forceinline__ int fwd_store_float4(int tid, int t) {
-    return ((((tid & 15) * 8 + t) << 6) + 16 * ((tid >> 4) & 3) + (tid >> 6));
+// thread tid holding X[tid + 1024 r] in register r.
+// That is a permutation of the THREADS (same register index): the bins register r of thread (w, l) loads are held, after
+// a forward transform, by register r of thread w + 64 (l & 15) + 16 (l >> 4).  The forward kernels hand their outputs
+// over through the LDS (real parts, then imaginary parts; position tid + tid / 64 makes the gather conflict-free) so that
+// the global stores are whole KiB per wave instead of 16-byte pieces 8 KiB apart (pattern spectra are written every run).
+__device__ __forceinline__ void to_load_order(cpx (&v)[sushi_fft::PER], const int tid, float* lds) {
+    constexpr int P = FT + FT / 64;
+    const int src = (tid >> 6) + 64 * (tid & 15) + 16 * ((tid >> 4) & 3);
+    float* out = lds + tid + (tid >> 6);
+    const float* in = lds + src + (src >> 6);
+    __syncthreads();                                             // the transform's own use of the buffer is over
+#pragma unroll
+    for (int r = 0; r < sushi_fft::PER; ++r) out[P * r] = v[r].x;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < sushi_fft::PER; ++r) v[r].x = in[P * r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < sushi_fft::PER; ++r) out[P * r] = v[r].y;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < sushi_fft::PER; ++r) v[r].y = in[P * r];
 }
+static_assert(sushi_fft::PER * (FT + FT / 64) <= LDS_FLOATS, "the hand-over fits the transform's buffer");
 
 // exp(-2*pi*i*n/16384), n = 0..16383, float32 rounded from float64 (generated by sushi_amd/build.py)
 __device__ const float g_twiddle[2 * sushi_fft::TWIDDLE_N] = {
@@ -100,10 +120,11 @@ void spectra_kernel(const T* __restrict__ raw, int64_t n, cpx* __restrict__ spec
         v[r].y = (e + FH) < n ? xb : 0.f;
     }
     sushi_fft::fft_split<FFT_LOGN, -1>(v, tid, lds, tw);
+    to_load_order(v, tid, lds);
     float4* __restrict__ out = reinterpret_cast<float4*>(spec + (size_t)j * FN);
 #pragma unroll
     for (int t = 0; t < sushi_fft::PER / 2; ++t)
-        out[fwd_store_float4(tid, t)] = float4{v[2 * t].x, v[2 * t].y, v[2 * t + 1].x, v[2 * t + 1].y};
+        out[sushi_fft::wslot_float4(tid, t)] = float4{v[2 * t].x, v[2 * t].y, v[2 * t + 1].x, v[2 * t + 1].y};
 }
 
 // last search of [0, n) whose first_seg is <= x
@@ -181,11 +202,12 @@ void tspec_kernel(TspecArgs a) {
         v[r].y = 0.f;
     }
     sushi_fft::fft_split<FFT_LOGN, -1>(v, tid, lds, tw);
+    to_load_order(v, tid, lds);
     float4* __restrict__ out = reinterpret_cast<float4*>(a.tspec + (size_t)blockIdx.x * FN);
     const float sc = 1.0f / (float)FN;
 #pragma unroll
     for (int t = 0; t < sushi_fft::PER / 2; ++t)
-        out[fwd_store_float4(tid, t)] = float4{v[2 * t].x * sc, -v[2 * t].y * sc, v[2 * t + 1].x * sc, -v[2 * t + 1].y * sc};
+        out[sushi_fft::wslot_float4(tid, t)] = float4{v[2 * t].x * sc, -v[2 * t].y * sc, v[2 * t + 1].x * sc, -v[2 * t + 1].y * sc};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -233,7 +255,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 }
 
 constexpr int MAC_SMAX_SHORT = mac_class_smax(MAC_SHORT_CLASSES - 1);   // 18: mac_kernel
-constexpr int MAC_SMAX_LONG = mac_class_smax(MAC_CLASSES - 1);           // 36: mac_long_kernel
+constexpr int MAC_SMAX_LONG = mac_class_smax(MAC_CLASSES - 1);           // 30: mac_long_kernel
 constexpr int MAC_CH = MAC_ZR;                   // rows one load instruction brings (lane = row x bin pair)
 static_assert(MAC_CH <= MAC_SPW, "a load's rows are spread over the search slots");
 constexpr int MAC_AHEAD_ROWS = 36;               // rows in flight per wave (mac_kernel: a multiple of each of its SMAX; mac_long_kernel: one group): 4.5 KB
@@ -393,7 +415,7 @@ void mac_kernel(MacArgs a) {
     }
 }
 
-// Patterns of 19 .. 36 segments (and, 36 at a time, longer ones): up to 36 pattern spectra per lane, two waves per SIMD.
+// Patterns of 19 .. 30 segments (and, 30 at a time, longer ones): up to 30 pattern spectra per lane, two waves per SIMD.
 // One pass instead of mac_kernel's two with Y read back in between (BASELINE configs[4]: half of the events).
 __global__ __launch_bounds__(MAC_THREADS, 2)
 void mac_long_kernel(MacArgs a) {
@@ -403,8 +425,7 @@ void mac_long_kernel(MacArgs a) {
     const int* __restrict__ item = a.items + (size_t)item_idx * (1 + MAC_SPW);
     switch (item[0]) {
         case 3: mac_item<24, MAC_SMAX_LONG>(a, item, f2, slot, zring[wave]); break;
-        case 4: mac_item<30, MAC_SMAX_LONG>(a, item, f2, slot, zring[wave]); break;
-        default: mac_item<36, MAC_SMAX_LONG>(a, item, f2, slot, zring[wave]); break;
+        default: mac_item<30, MAC_SMAX_LONG>(a, item, f2, slot, zring[wave]); break;
     }
 }
 
@@ -463,30 +484,32 @@ struct PairScores {
 __device__ __forceinline__ float ccoeff_cd(float inv_sqrt_m) { return 28.0f + 512.0f * inv_sqrt_m; }
 __device__ __forceinline__ float ccoeff_kn(float inv_sqrt_m) { return FFT_KE + 8.0f + 256.0f * inv_sqrt_m; }
 
-// One pair: load Y, inverse transform, f32 scores.  Returns through `ps`; `plo`/`phi` bound the valid positions.
+// Y of one pair into the registers of the inverse transform.  Y is stored in the order the transform loads it: one 16-byte
+// load brings registers 2t and 2t + 1, a wave's load instruction one contiguous KiB.  Issued before anything else a
+// workgroup does: the address needs the pair index only, and the search's descriptor and constants (two more dependent
+// loads) are not needed before the epilogue -- with two workgroups per CU every serial hop at a workgroup's start is CU time.
+__device__ __forceinline__ void load_y(cpx (&v)[sushi_fft::PER], const cpx* __restrict__ yin, const int tid) {
+#pragma unroll
+    for (int t = 0; t < sushi_fft::PER / 2; ++t) {
+        const float4 two = reinterpret_cast<const float4*>(yin)[sushi_fft::wslot_float4(tid, t)];
+        v[2 * t] = cpx{two.x, two.y};
+        v[2 * t + 1] = cpx{two.z, two.w};
+    }
+}
+
+// One pair: inverse transform of the loaded Y, f32 scores.  Returns through `ps`; `plo`/`phi` bound the valid positions.
 // METHOD 0  score = sum (T - I)^2 / sqrt(sum T^2 * sum I^2), everything UNCENTRED: the f32 error of the FFT'd cross term
 //           is then bounded by FFT_KE * eps * |T| * |Z| (sushi_common.hpp), i.e. in score units 2 * FFT_KE * eps * |Z| / |window|.
 // METHOD 1  score = 1 - (sum T I - sum I * mean T) / sqrt(sum (T - mean T)^2 * (sum I^2 - (sum I)^2 / M)): the same cross
 //           term with the same bound; the window sums come from the stream's second relative prefix (srel / sbase).
 template <int METHOD>
-__device__ __forceinline__ void score_pair(const IfftArgs& a, const cpx* __restrict__ yin, const SearchDesc& sd,
+__device__ __forceinline__ void score_pair(const IfftArgs& a, cpx (&v)[sushi_fft::PER], const SearchDesc& sd,
                                            const TemplConsts& tc, const int64_t pairI, float* lds, const int tid,
                                            const sushi_fft::WTwiddles& tw, PairScores& ps, int& plo_out, int& phi_out,
                                            float& zn_out) {
     constexpr bool CC = METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED;
     constexpr int GQM = GQ;                                      // (GQ / 2 for METHOD 1 was tried: more scratch, not less)
     constexpr int NG = 2 * HPT / GQM;
-    cpx v[sushi_fft::PER];
-    {
-        // Y is stored in the order this transform loads it: one 16-byte load brings registers 2t and 2t + 1, a wave's
-        // load instruction one contiguous KiB
-#pragma unroll
-        for (int t = 0; t < sushi_fft::PER / 2; ++t) {
-            const float4 two = reinterpret_cast<const float4*>(yin)[sushi_fft::wslot_float4(tid, t)];
-            v[2 * t] = cpx{two.x, two.y};
-            v[2 * t + 1] = cpx{two.z, two.w};
-        }
-    }
     const int M = sd.tmpl_len;
     const int64_t P = sd.n_pos;
     const int64_t w = sd.win_start;
@@ -726,51 +749,55 @@ template <int METHOD>
 __global__ __launch_bounds__(FT, 8)
 void ifft_kernel(IfftArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    __shared__ float redf[FT / 64], redr[FT / 64];
-    __shared__ unsigned long long cl[FFT_CAND];
-    __shared__ unsigned long long audit;
-    __shared__ int lmin_pos;
-    __shared__ int ccnt, unc_listed;
+    __shared__ unsigned red_min, red_rs;        // float bits (both >= 0: unsigned order == float order)
+    __shared__ int ccnt, unc_any;
     const int tid = threadIdx.x;
-    const sushi_fft::WTwiddles tw = sushi_fft::load_wtwiddles<1>(tid, twiddles());
-    const int lane = tid & 63, wave = tid >> 6;
     // which pair: by default the workgroup index; with a schedule the pairs that read the same region of the
     // destination stream run back to back on one XCD, so that the prefix-sum lines they share are fetched into that
     // XCD's L2 once instead of once per search
     const int pr = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    cpx v[sushi_fft::PER];
+    load_y(v, a.y + (size_t)pr * FN, tid);                             // in flight while the descriptors below arrive
+    const sushi_fft::WTwiddles tw = sushi_fft::load_wtwiddles<1>(tid, twiddles());
+    const int lane = tid & 63;
     const int k = __builtin_amdgcn_readfirstlane(a.pairmap[pr]);       // wave-uniform: everything derived from it is scalar
     const SearchDesc sd = a.searches[k];
     const int i = a.sub_first_pair + pr - sd.first_pair;
     const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
     const TemplConsts tc = a.tconst[k];
+    // the pair's row of the candidate array starts as all NO_KEY (memset at the start of the run): only what exists is written
     unsigned long long* __restrict__ cout = a.cand + (size_t)pr * FFT_ROW;
     if (METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED && tc.flat) {
         // a pattern without variance: cv2's result is all ones (refine_kernel answers position 0); nothing to rank
-        if (tid < FFT_ROW) cout[tid] = tid == FFT_CAND + 1 ? 0ull : NO_KEY;
+        if (tid == 0) cout[FFT_CAND + 1] = 0ull;
         return;
     }
-    if (tid == 0) { ccnt = 0; unc_listed = 0; lmin_pos = 0x7fffffff; audit = NO_KEY; }   // read after the barriers inside the transform
+    if (tid == 0) { ccnt = 0; unc_any = 0; red_min = 0x7f800000u; red_rs = 0u; }   // read after the barriers inside the transform
     PairScores ps;
     int plo, phi;
     float zn;
-    score_pair<METHOD>(a, a.y + (size_t)pr * FN, sd, tc, lay.pair0 + i, lds, tid, tw, ps, plo, phi, zn);
-    // minimum of the pair: values first (one v_min per position, 32-bit wave reduction), then the lowest
-    // position holding that value (the few lanes that get into the candidate loop settle it); alongside it the
-    // largest 1/|window| for the error bound
+    score_pair<METHOD>(a, v, sd, tc, lay.pair0 + i, lds, tid, tw, ps, plo, phi, zn);
+    // minimum of the pair and the largest 1/|window| (error bound): 32-bit wave reductions, then one LDS atomic each per
+    // wave and ONE barrier -- the workgroup's tail is serial time on a CU that holds two workgroups
     float wmin = ps.best, wrs = ps.max_rs;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         wmin = fminf(wmin, __shfl_down(wmin, d, 64));
         wrs = fmaxf(wrs, __shfl_down(wrs, d, 64));
     }
-    if (lane == 0) { redf[wave] = wmin; redr[wave] = wrs; }
+    if (lane == 0) {
+        atomicMin(&red_min, __float_as_uint(wmin));                    // scores are >= 0 or +inf
+        atomicMax(&red_rs, __float_as_uint(wrs));
+    }
+    if (METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED && __ballot(ps.any_uncertain) != 0ull && lane == 0) unc_any = 1;
     __syncthreads();
-    float lmin_s = redf[0], rs_max = redr[0];
-#pragma unroll
-    for (int ww = 1; ww < FT / 64; ++ww) { lmin_s = fminf(lmin_s, redf[ww]); rs_max = fmaxf(rs_max, redr[ww]); }
+    const float lmin_s = __uint_as_float(red_min), rs_max = __uint_as_float(red_rs);
     const bool have_min = lmin_s < __builtin_inff();
     const float e_model = pair_error_model<METHOD>(zn, rs_max, tc);
     const float e_pair = fmaxf(0.5f * a.delta, e_model);
+    // positions leave this kernel relative to the search's window: p = (pair's first sample + pos) - win_start
+    const int64_t shift = (lay.pair0 + i) * (int64_t)FFT_STEP * FFT_SEG - sd.win_start;
+    if (tid == 0) cout[FFT_CAND + 1] = ((unsigned long long)__float_as_uint(e_model) << 32) | __float_as_uint(e_pair);
     // a position can be the search's minimum only if score - e <= (smallest score + e) of the search; inside the
     // pair that is score <= lmin_s + 2 e (refine_kernel applies the search-wide threshold to the stored lower bounds);
     // uncertain positions (METHOD 1) always can
@@ -778,17 +805,26 @@ void ifft_kernel(IfftArgs a) {
     const bool mine = METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED ? ((ps.best <= thr && have_min) || ps.any_uncertain)
                                                                : (ps.best <= thr && have_min);
     if (mine) {                                                 // few lanes (often one wave) get past this
+        // slots 0 .. FFT_CAND-1: candidates, written where they are found; whoever draws slot FFT_CAND writes the marker
+        // "more candidate positions than slots" (a lower bound of everything unlisted, position 0xffffffff): refine_kernel
+        // flags the search if that bound is under the search's threshold
+        const float unlisted_lb = (METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED && unc_any) ? 0.f : fmaxf(lmin_s - e_pair, 0.f);
+        int lowest = 0x7fffffff;                                // lowest position of this thread that holds the minimum
 #pragma unroll
         for (int q = 0; q < 2 * HPT; ++q) {
             const float sc = ps.scores[q];
             if (sc <= thr && sc < __builtin_inff()) {
                 const int pos = tid + FT * (q % HPT) + (q / HPT) * FH;
-                if (sc == lmin_s) atomicMin(&lmin_pos, pos);
-                if (METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED && sc < 0.f) unc_listed = 1;
+                if (sc == lmin_s) lowest = pos < lowest ? pos : lowest;
                 const int slot = atomicAdd(&ccnt, 1);
-                if (slot < FFT_CAND) cl[slot] = make_key(fmaxf(sc - e_pair, 0.f), (unsigned)pos);
+                if (slot < FFT_CAND) cout[slot] = make_key(fmaxf(sc - e_pair, 0.f), (unsigned)((int64_t)pos + shift));
+                else if (slot == FFT_CAND) cout[FFT_CAND] = make_key(unlisted_lb, 0xffffffffu);
             }
         }
+        // the pair's upper bound (its smallest score + e) at the lowest position holding it: ties inside a pair are rare, and
+        // atomicMin over the keys settles them by position
+        if (lowest != 0x7fffffff)
+            atomicMin(a.gkeys + a.first_search + k, make_key(lmin_s + e_pair, (unsigned)((int64_t)lowest + shift)));
     }
     // the pair's audit position: one pseudo-random position (by a hash of the pair index) leaves with its plain f32
     // score whether or not it is a candidate; refine_kernel evaluates one of them per search exactly
@@ -800,35 +836,9 @@ void ifft_kernel(IfftArgs a) {
             float sc = __builtin_inff();
 #pragma unroll
             for (int q = 0; q < 2 * HPT; ++q) sc = q == qa ? ps.scores[q] : sc;
-            if (sc >= 0.f && sc < __builtin_inff()) audit = make_key(sc, (unsigned)pos_a);
+            if (sc >= 0.f && sc < __builtin_inff()) cout[FFT_CAND + 2] = make_key(sc, (unsigned)((int64_t)pos_a + shift));
         }
     }
-    __syncthreads();
-    // positions leave this kernel relative to the search's window: p = (pair's first sample + pos) - win_start
-    const int64_t shift = (lay.pair0 + i) * (int64_t)FFT_STEP * FFT_SEG - sd.win_start;
-    const int cnt = ccnt;
-    if (tid < FFT_CAND) {
-        // (an opaque copy: otherwise 8 * tid, first needed for the twiddle table, is kept for this store across the
-        // whole kernel -- in scratch, the transform has no register to spare)
-        int t = tid;
-        asm volatile("" : "+v"(t));
-        unsigned long long e = NO_KEY;
-        if (t < cnt) e = (cl[t] & 0xffffffff00000000ull) | (unsigned)((int64_t)key_pos(cl[t]) + shift);
-        cout[t] = e;
-    }
-    // slot FFT_CAND: "more candidate positions than slots" (lower bound of the pair's minimum, position
-    // 0xffffffff); refine_kernel flags the search if that bound is under the search's threshold
-    if (tid == FFT_CAND)
-        cout[FFT_CAND] = cnt > FFT_CAND ? make_key((have_min && !unc_listed) ? fmaxf(lmin_s - e_pair, 0.f) : 0.f, 0xffffffffu)
-                                        : NO_KEY;
-    if (tid == FFT_CAND + 1)
-        cout[FFT_CAND + 1] = ((unsigned long long)__float_as_uint(e_model) << 32) | __float_as_uint(e_pair);
-    if (tid == FFT_CAND + 2) {
-        const unsigned long long au = audit;
-        cout[FFT_CAND + 2] = au == NO_KEY ? NO_KEY : ((au & 0xffffffff00000000ull) | (unsigned)((int64_t)key_pos(au) + shift));
-    }
-    if (tid == 0 && have_min)
-        atomicMin(a.gkeys + a.first_search + k, make_key(lmin_s + e_pair, (unsigned)((int64_t)lmin_pos + shift)));
 }
 
 // Collection pass over the flagged searches of a sub-batch: the same transforms and scores again (bit for bit), now
@@ -867,7 +877,9 @@ void collect_kernel(IfftArgs a) {
             if (!everything) {
                 PairScores ps;
                 float zn;
-                score_pair<METHOD>(a, a.y + (size_t)pr * FN, sd, tc, lay.pair0 + i, lds, tid, tw, ps, plo, phi, zn);
+                cpx v[sushi_fft::PER];
+                load_y(v, a.y + (size_t)pr * FN, tid);
+                score_pair<METHOD>(a, v, sd, tc, lay.pair0 + i, lds, tid, tw, ps, plo, phi, zn);
                 float wrs = ps.max_rs;
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) wrs = fmaxf(wrs, __shfl_down(wrs, d, 64));
@@ -1419,6 +1431,9 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         prof_end(pc, t0, SUSHI_HIP_STAGE_MAC, st);
 
         t0 = prof_begin(pc, st);
+        // the candidate rows start empty: ifft_kernel writes only the entries that exist
+        if (hipMemsetAsync(cand, 0xff, (size_t)sbt.pairs * FFT_ROW * sizeof(unsigned long long), st) != hipSuccess)
+            return SUSHI_HIP_ELAUNCH;
         IfftArgs ia;
         memset(&ia, 0, sizeof(ia));
         ia.y = y; ia.searches = searches_dev + sbt.a0; ia.n_sub = n_sub; ia.first_search = sbt.a0;

@@ -410,7 +410,7 @@ def test_fft_spectra_match_numpy():
 @pytest.mark.parametrize("dtype", [np.float32, np.uint8])
 def test_fft_every_segment_count_class_and_chunked_patterns(oracle, dtype):
     """Patterns of 1 .. 74 segments in one batch: every class of mac_kernel (up to 6 / 12 / 18 segments) and of
-    mac_long_kernel (24 / 30 / 36), and patterns beyond 36 segments, which take several accumulating passes; mixed in one
+    mac_long_kernel (24 / 30), and patterns beyond 30 segments, which take several accumulating passes; mixed in one
     batch so that waves hold searches of different lengths.  All identical to the oracle."""
     rng = np.random.default_rng(29)
     n_dst, n_src = 700000, 400000
