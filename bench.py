@@ -492,9 +492,24 @@ def main():
                   "events_beyond_one_sample_of_planted": beyond_planted,
                   "oracle_sample_searches": len(cpu_results),
                   "score_tolerance": "1e-4*score + 2.5e-7 (one float32 ulp of cv2's stored corr)"}
+        ties = 0
         if cpu_results:
             ks = sorted(cpu_results)
             ie = np.array([abs(int(idx_all[k]) - cpu_results[k][0]) for k in ks])
+            if args.sample_type == "float32" and ie.max() > 0:
+                # a different index is a tie, not an error, if the oracle itself scores the two positions within the float32
+                # quantum of cv2's stored cross term (tests/test_gpu_parity.py _check_f32): material that repeats exactly (a
+                # recurring jingle, a held tone) ties exactly, the product returns the FIRST such position from exact
+                # arithmetic, the oracle's float64 FFT may round a later one a quantum lower
+                from oracle import oracle as O
+                for j, k in enumerate(ks):
+                    if ie[j] == 0:
+                        continue
+                    off, m, ws, p = offs[k], lens[k], wst[k], npos[k]
+                    row = O.match_template_fft(dst.data[0][ws:ws + p + m - 1], src.data[0][off:off + m], method=args.method)[0]
+                    if abs(float(row[int(idx_all[k])]) - float(row[cpu_results[k][0]])) <= SCORE_ATOL:
+                        ie[j] = 0
+                        ties += 1
             ae = np.array([abs(float(score_all[k]) - cpu_results[k][1]) for k in ks])
             # excess over the parity bound |d| <= 1e-4*score + 2.5e-7 (tests/test_gpu_parity.py); <= 1 passes
             se = np.array([abs(float(score_all[k]) - cpu_results[k][1]) / (SCORE_RTOL * abs(cpu_results[k][1]) + SCORE_ATOL)
@@ -502,7 +517,8 @@ def main():
             parity.update(max_idx_err_vs_oracle_sample=int(ie.max()),
                           max_score_err_over_tolerance_vs_oracle_sample=float(se.max()),
                           max_abs_score_err_vs_oracle_sample=float(ae.max()),
-                          oracle_sample_hard_searches=int(sum(1 for k in ks if hard_mask[k])))
+                          oracle_sample_hard_searches=int(sum(1 for k in ks if hard_mask[k])),
+                          oracle_sample_exact_ties_at_another_index=ties)
             if diag_ps is not None:
                 fl = diag_ps["flagged_per_search"]
                 parity["oracle_sample_flagged_searches"] = int(sum(1 for k in ks if fl[k]))

@@ -229,13 +229,15 @@ constexpr int WROW = 18;                       // floats per padded run of 16
 constexpr int W_LDS_FLOATS = WROW * 1024;      // 72 KB: the workgroup exchange; a wave's row exchange uses floats [1152 w, 1152 w + 1152)
 
 // float4 index, inside a stored spectrum of N complex values, of the register pair (2t, 2t+1) of thread `tid`
-SUSHI_HD int wslot_float4(int tid, int t) { return (((tid >> 6) * 8 + t) << 6) + (tid & 63); }
+// (registers 4u .. 4u+3 of a thread are neighbours in a stored row, bin pairs t = 2u and 2u + 1: a product row Y, kept as
+// packed halves, is then loaded 16 bytes = four registers at a time)
+SUSHI_HD int wslot_float4(int tid, int t) { return (((((tid >> 6) * 4 + (t >> 1)) << 6) + (tid & 63)) << 1) + (t & 1); }
 // the frequency bin a thread's register d1 holds when it loads a stored spectrum
 SUSHI_HD int wbin(int tid, int d1) { return (tid >> 6) + 1024 * d1 + 64 * (tid & 15) + 16 * ((tid >> 4) & 3); }
 // complex index, inside a stored spectrum, of bin f
 SUSHI_HHD int wslot_of_bin(int f) {
     const int w = f & 15, d3 = (f >> 4) & 3, d2 = (f >> 6) & 15, d1 = f >> 10;
-    return ((((w * 8 + (d1 >> 1)) << 6) + 16 * d3 + d2) << 1) + (d1 & 1);
+    return (((((w * 4 + (d1 >> 2)) << 6) + 16 * d3 + d2) << 1) + ((d1 >> 1) & 1)) * 2 + (d1 & 1);
 }
 
 struct WTwiddles { cpx g2, q3, p4; };

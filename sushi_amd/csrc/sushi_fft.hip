@@ -62,6 +62,28 @@ constexpr int RPB = FFT_SEG / FT;                      // of which per block
 static_assert(FH % FT == 0 && FFT_SEG % FT == 0 && HPT == FFT_VB * RPB, "position layout");
 static_assert(HPT <= sushi_fft::PER, "a thread's valid outputs are a prefix of its transform outputs");
 constexpr int LDS_FLOATS = sushi_fft::lds_floats<FFT_LOGN>();
+
+// ---- the products Y leave mac_kernel as packed halves (half the bytes of the step's dominant traffic) -------------
+// Two things make 11 bits enough for a stage that only ranks:
+//  * block spectra are of the CENTRED destination samples (x - c, c = 0.5 | 128), patterns stay as they are:
+//        y'[p] = sum_m T[m] (I[p+m] - c) = sum T I - c sum T
+//    -- the correction is one constant per search -- and Y then carries no product of two DC terms: its energy, and with
+//    it the quantisation noise of every position, is that of pattern x centred audio instead of ~M/4 at every position;
+//  * the noise is modelled per pair from the energy of the Y row actually loaded (Parseval), added to the pair's error
+//    bound, and checked like the rest of the bound (candidates and one audited non-candidate per search, refine_kernel).
+// The constant c is the stream's own mean (any constant is exact; the mean keeps DC out whatever level the data sits at).
+// Pattern spectra carry a power-of-two scale per search so that no product can overflow a half whatever the magnitude of
+// the data: |Y(f)| <= sum_s |Tt_s(f)| * max_j |Z_j(f)| <= (64 sqrt(n_seg) |T| / N) * (sqrt(7 * 4096) sqrt(E7)), E7 = the
+// largest centred energy of FFT_STEP + 1 consecutive blocks of the stream (SushiHipStream.stats); typical products sit
+// ~sqrt(N) below that bound, twenty binary orders above the smallest normal half.
+__device__ __forceinline__ float y_scale_for(double tnorm, int n_seg, double e7) {
+    const double bound = (64.0 * sqrt((double)n_seg) * tnorm / (double)FN) * (169.33 * sqrt(e7));
+    if (!(bound > 0.0)) return 1.0f;
+    int k = (int)floor(log2(32768.0 / bound));
+    k = k < -60 ? -60 : (k > 60 ? 60 : k);
+    return (float)ldexp(1.0, k);
+}
+constexpr float Y_KQ = 8.0f;                  // the quantisation term of a pair's bound, in standard deviations
 static_assert(FFT_LOGN == 14 && sushi_fft::W_LDS_FLOATS <= LDS_FLOATS && FT == sushi_fft::WNT, "the wave plan is the 16384-point inverse");
 
 // Spectra are STORED in the order the inverse transform loads them (fft_core.hpp "Wave plan": wslot_of_bin): block
@@ -103,7 +125,8 @@ __device__ __forceinline__ const cpx* twiddles() { return reinterpret_cast<const
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(FT)
-void spectra_kernel(const T* __restrict__ raw, int64_t n, cpx* __restrict__ spec) {
+void spectra_kernel(const T* __restrict__ raw, int64_t n, cpx* __restrict__ spec, const double* __restrict__ stats) {
+    const float centre = (float)stats[1];
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     const int tid = threadIdx.x;
     const sushi_fft::Twiddles tw = sushi_fft::load_twiddles<FFT_LOGN, -1>(tid, twiddles());
@@ -114,8 +137,8 @@ void spectra_kernel(const T* __restrict__ raw, int64_t n, cpx* __restrict__ spec
     for (int r = 0; r < sushi_fft::PER; ++r) {
         // unconditional loads from clamped addresses + select: the loads stay batched
         const int64_t e = base + sushi_fft::in_index<FFT_LOGN>(tid, r);
-        const float xa = (float)raw[e < n ? e : n - 1];   // the FFT path works on the samples as they are
-        const float xb = (float)raw[(e + FH) < n ? (e + FH) : n - 1];
+        const float xa = (float)raw[e < n ? e : n - 1] - centre;      // centred (above); zeros past the end of the stream
+        const float xb = (float)raw[(e + FH) < n ? (e + FH) : n - 1] - centre;
         v[r].x = e < n ? xa : 0.f;
         v[r].y = (e + FH) < n ? xb : 0.f;
     }
@@ -147,6 +170,8 @@ struct TemplConsts {
     float inv_tnorm_c;   // 1 / sqrt(sum (T - mean T)^2); 0 for a flat pattern
     float inv_m;         // 1 / M
     int flat;            // the pattern has no variance: cv2's result is all ones
+    float c_sum_t;       // c * sum T: sum T I = y' + c_sum_t (block spectra are of the centred destination samples)
+    float inv_scale;     // 1 / the power-of-two scale of this search's pattern spectra (and so of its products)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -165,6 +190,7 @@ struct TspecArgs {
     const double* src_s1;
     const double* src_s2;
     double centre;
+    const double* dst_stats;          // the searched stream's stats: [0] largest energy of a pair's span, [1] its centring constant
 };
 
 template <typename T>
@@ -178,6 +204,8 @@ void tspec_kernel(TspecArgs a) {
     const SearchDesc sd = a.searches[k];
     const int s = seg - sd.first_seg;
     const int M = sd.tmpl_len;
+    const TemplStats ts_all = templ_stats(a.src_s1, a.src_s2, sd.tmpl_off, M, a.centre);
+    const float scale = y_scale_for(ts_all.tnorm, (M + FFT_SEG - 1) / FFT_SEG, a.dst_stats[0]);
     if (s == 0) {
         const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, M);
         int* __restrict__ pm = a.pairmap + (sd.first_pair - a.sub_first_pair);
@@ -188,6 +216,7 @@ void tspec_kernel(TspecArgs a) {
             tc.tU = ts.tU; tc.inv_tnorm = (float)(1.0 / ts.tnorm); tc.tnorm = (float)ts.tnorm;
             tc.tmean = (float)ts.tmean; tc.flat = ts.flat ? 1 : 0;
             tc.inv_tnorm_c = ts.flat ? 0.f : (float)(1.0 / ts.tnorm_c); tc.inv_m = (float)(1.0 / (double)M);
+            tc.c_sum_t = (float)(a.dst_stats[1] * ts.tS1); tc.inv_scale = 1.0f / scale;
             a.tconst[k] = tc;
         }
     }
@@ -204,7 +233,7 @@ void tspec_kernel(TspecArgs a) {
     sushi_fft::fft_split<FFT_LOGN, -1>(v, tid, lds, tw);
     to_load_order(v, tid, lds);
     float4* __restrict__ out = reinterpret_cast<float4*>(a.tspec + (size_t)blockIdx.x * FN);
-    const float sc = 1.0f / (float)FN;
+    const float sc = scale / (float)FN;
 #pragma unroll
     for (int t = 0; t < sushi_fft::PER / 2; ++t)
         out[sushi_fft::wslot_float4(tid, t)] = float4{v[2 * t].x * sc, -v[2 * t].y * sc, v[2 * t + 1].x * sc, -v[2 * t + 1].y * sc};
@@ -228,7 +257,7 @@ struct MacArgs {
     const float4* spec;               // destination spectra, as pairs of bins
     int64_t spec_blocks;              // blocks of the stream; block `spec_blocks` is all zero
     const float4* tspec;
-    float4* y;                        // [pairs of the sub-batch][FN/2]
+    uint2* y;                         // [pairs of the sub-batch][FN/2]: two bins = four halves per entry
     const SearchDesc* searches;       // the sub-batch's searches
     const int* items;                 // [n_items][1 + MAC_SPW]: segment-count class, then search indices inside the sub-batch (-1 = none)
     int n_items;
@@ -272,7 +301,7 @@ template <int SMAX, bool ACCUM, int ZROWS>
 __device__ __forceinline__ void mac_chunk(const MacArgs& a, const int c0, const int wv_first, const int wv_last,
                                           const long long pair_lo, const long long pair_hi, const bool lane_chunk,
                                           const sushi_mac::c2 (&tt)[SMAX], const float4* __restrict__ zsp, const int z_zero,
-                                          float4* __restrict__ yout, float4* __restrict__ dummy, const int slot,
+                                          uint2* __restrict__ yout, uint2* __restrict__ dummy, const int slot,
                                           const int fb, float4 (*zw)[ZROWS + 1][MAC_BPW]) {
     using sushi_mac::c2;
     constexpr int STEP = FFT_STEP;
@@ -322,13 +351,20 @@ __device__ __forceinline__ void mac_chunk(const MacArgs& a, const int c0, const 
             for (int c = 0; c < NC; ++c) rq[((t + 1) % LA) * NC + c] = load_rows(jg + c0 + SMAX * (1 + LA) + MAC_CH * c);
             auto get_z = [&](const int u) { return as_c2(zw[t & 1][u][fb]); };
             auto store = [&](const int i, const bool valid, const c2 v) {
-                typedef float f4 __attribute__((ext_vector_type(4)));
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                 // (a lane-predicated store instead of the dummy line was tried: the compiler branches around it and
                 // falls back to draining the load queue, tools/experiments/README.md)
                 const bool ok = valid && lane_chunk && jg <= wv_last;
-                f4* __restrict__ dst = reinterpret_cast<f4*>(ok ? yout + (size_t)i * HALF : dummy);
-                f4 o = {v.ax, v.ay, v.bx, v.by};
-                if (ACCUM) { const f4 prev = *dst; o += prev; }
+                u2* __restrict__ dst = reinterpret_cast<u2*>(ok ? yout + (size_t)i * HALF : dummy);
+                float ax = v.ax, ay = v.ay, bx = v.bx, by = v.by;
+                if (ACCUM) {                                    // patterns beyond one pass: the row accumulates (in halves)
+                    const u2 prev = *dst;
+                    const h2 p0 = __builtin_bit_cast(h2, prev.x), p1 = __builtin_bit_cast(h2, prev.y);
+                    ax += (float)p0.x; ay += (float)p0.y; bx += (float)p1.x; by += (float)p1.y;
+                }
+                const h2 q0 = {(_Float16)ax, (_Float16)ay}, q1 = {(_Float16)bx, (_Float16)by};   // v_cvt_pk_f16_f32: round to nearest even
+                const u2 o = {__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)};
                 // Y is streamed once and read back once by another kernel: non-temporal stores keep the block spectra in
                 // L2.  A store with dummy lanes in it goes the write-back way instead (one store instruction on either
                 // path): the dummy lines are overwritten in L2 again and again and never reach HBM, whereas non-temporal
@@ -365,11 +401,11 @@ __device__ __forceinline__ void mac_item(const MacArgs& a, const int* __restrict
     const int wv_last = __builtin_amdgcn_readfirstlane(wave_max_i32(jb1));
     const int wv_seg = __builtin_amdgcn_readfirstlane(wave_max_i32(n_seg));
     const float4* __restrict__ tsp = a.tspec + (size_t)first_seg * HALF + f2;
-    float4* __restrict__ yout = a.y + (size_t)first_pair * HALF + f2;
+    uint2* __restrict__ yout = a.y + (size_t)first_pair * HALF + f2;
     const float4* __restrict__ zsp = a.spec + f2;
     // one 16-byte slot per wave: the invalid lanes of a store instruction then add one request to it instead of a line per
     // search slot (a fifth of mac_kernel's write requests were dummy lines, and the CU's L1 write path is what it waits for)
-    float4* __restrict__ dummy = a.dummy + (size_t)(blockIdx.x % MAC_DUMMY_LINES) * MAC_THREADS + (threadIdx.x & ~63);
+    uint2* __restrict__ dummy = reinterpret_cast<uint2*>(a.dummy + (size_t)(blockIdx.x % MAC_DUMMY_LINES) * MAC_THREADS + (threadIdx.x & ~63));
     const int z_zero = (int)(a.spec_blocks < 0x7fffffff ? a.spec_blocks : 0x7fffffff);
     auto as_c2 = [](const float4 v) { return c2{v.x, v.y, v.z, v.w}; };
     for (int c0 = 0; c0 < wv_seg; c0 += SMAX) {                 // patterns longer than SMAX segments: SMAX at a time
@@ -433,7 +469,8 @@ void mac_long_kernel(MacArgs a) {
 // Inverse transform of one block pair + fused scoring epilogue
 // ------------------------------------------------------------------------------------------
 struct IfftArgs {
-    const cpx* y;                     // [pairs of the sub-batch][FN]
+    const uint2* y;                   // [pairs of the sub-batch][FN / 2]: the products as packed halves
+    const double* dst_stats;          // [1]: the constant the block spectra are centred by
     const SearchDesc* searches;       // the sub-batch's searches
     int n_sub;
     int first_search;                 // global index of searches[0]
@@ -484,17 +521,26 @@ struct PairScores {
 __device__ __forceinline__ float ccoeff_cd(float inv_sqrt_m) { return 28.0f + 512.0f * inv_sqrt_m; }
 __device__ __forceinline__ float ccoeff_kn(float inv_sqrt_m) { return FFT_KE + 8.0f + 256.0f * inv_sqrt_m; }
 
-// Y of one pair into the registers of the inverse transform.  Y is stored in the order the transform loads it: one 16-byte
-// load brings registers 2t and 2t + 1, a wave's load instruction one contiguous KiB.  Issued before anything else a
+// Y of one pair (packed halves) into the registers of the inverse transform.  Y is stored in the order the transform loads
+// it: one 16-byte load brings four registers, a wave's load instruction one contiguous KiB.  Issued before anything else a
 // workgroup does: the address needs the pair index only, and the search's descriptor and constants (two more dependent
 // loads) are not needed before the epilogue -- with two workgroups per CU every serial hop at a workgroup's start is CU time.
-__device__ __forceinline__ void load_y(cpx (&v)[sushi_fft::PER], const cpx* __restrict__ yin, const int tid) {
+__device__ __forceinline__ float load_y(cpx (&v)[sushi_fft::PER], const uint2* __restrict__ yin, const int tid) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const uint4* __restrict__ yh = reinterpret_cast<const uint4*>(yin);
+    float q2 = 0.f;                                              // energy of this thread's part of the row (quantisation model)
 #pragma unroll
-    for (int t = 0; t < sushi_fft::PER / 2; ++t) {
-        const float4 two = reinterpret_cast<const float4*>(yin)[sushi_fft::wslot_float4(tid, t)];
-        v[2 * t] = cpx{two.x, two.y};
-        v[2 * t + 1] = cpx{two.z, two.w};
+    for (int u = 0; u < sushi_fft::PER / 4; ++u) {
+        const uint4 q = yh[(((tid >> 6) * 4 + u) << 6) + (tid & 63)];    // registers 4u .. 4u+3: eight halves
+        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const h2 h = __builtin_bit_cast(h2, w[j]);
+            v[4 * u + j] = cpx{(float)h.x, (float)h.y};
+            q2 = __builtin_fmaf(v[4 * u + j].x, v[4 * u + j].x, __builtin_fmaf(v[4 * u + j].y, v[4 * u + j].y, q2));
+        }
     }
+    return q2;
 }
 
 // One pair: inverse transform of the loaded Y, f32 scores.  Returns through `ps`; `plo`/`phi` bound the valid positions.
@@ -506,7 +552,7 @@ template <int METHOD>
 __device__ __forceinline__ void score_pair(const IfftArgs& a, cpx (&v)[sushi_fft::PER], const SearchDesc& sd,
                                            const TemplConsts& tc, const int64_t pairI, float* lds, const int tid,
                                            const sushi_fft::WTwiddles& tw, PairScores& ps, int& plo_out, int& phi_out,
-                                           float& zn_out) {
+                                           float& zn_out, float& znc_out) {
     constexpr bool CC = METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED;
     constexpr int GQM = GQ;                                      // (GQ / 2 for METHOD 1 was tried: more scratch, not less)
     constexpr int NG = 2 * HPT / GQM;
@@ -584,7 +630,7 @@ __device__ __forceinline__ void score_pair(const IfftArgs& a, cpx (&v)[sushi_fft
     // samples that enters this pair's transforms (error bound).
     double sb[2 * FFT_VB], eb[2 * FFT_VB + 1];
     double sb1[CC ? 2 * FFT_VB : 1], eb1[CC ? 2 * FFT_VB + 1 : 1];
-    double span_end;
+    double span_end, span_start1, span_end1;                     // (sums of the samples over the span: its centred energy)
     const int n_seg = (M + FFT_SEG - 1) / FFT_SEG;
     if (kA + n_seg + 2 * FFT_VB <= a.nb) {                       // away from the end of the stream: consecutive entries, wide loads
 #pragma unroll
@@ -592,6 +638,8 @@ __device__ __forceinline__ void score_pair(const IfftArgs& a, cpx (&v)[sushi_fft
 #pragma unroll
         for (int c = 0; c < 2 * FFT_VB + 1; ++c) eb[c] = a.ubase[kA + Mh + c];
         span_end = a.ubase[kA + n_seg + 2 * FFT_VB];
+        span_start1 = a.sbase[kA];
+        span_end1 = a.sbase[kA + n_seg + 2 * FFT_VB];
         if (CC) {
 #pragma unroll
             for (int c = 0; c < 2 * FFT_VB; ++c) sb1[c] = a.sbase[kA + c];
@@ -616,6 +664,9 @@ __device__ __forceinline__ void score_pair(const IfftArgs& a, cpx (&v)[sushi_fft
         int64_t bi = kA + n_seg + 2 * FFT_VB;
         bi = bi < a.nb ? bi : a.nb;
         span_end = a.ubase[bi];
+        span_end1 = a.sbase[bi];
+        int64_t b0 = kA < a.nb ? kA : a.nb;
+        span_start1 = a.sbase[b0];
     }
     sushi_fft::fft_wave<1>(v, tid, lds, tw);
     // keep the window loads below the last pass: hoisted above it (the scheduler's preference) they do not
@@ -653,7 +704,20 @@ __device__ __forceinline__ void score_pair(const IfftArgs& a, cpx (&v)[sushi_fft
     }
     const float zn = uniform((float)sqrt(fmax(span_end - sb[0], 0.0)));
     zn_out = zn;
-    const float tU = uniform((float)tc.tU);
+    {
+        // energy of the CENTRED samples that enter this pair's transforms (what the f32 error of the cross term scales with)
+        const int64_t s_lo = qbase < n ? qbase : n;
+        const int64_t s_hi64 = (kA + n_seg + 2 * FFT_VB) * (int64_t)FFT_SEG;
+        const int64_t s_hi = s_hi64 < n ? s_hi64 : n;
+        const double c = a.dst_stats[1];
+        const double e2 = (span_end - sb[0]) - 2.0 * c * (span_end1 - span_start1) + c * c * (double)(s_hi - s_lo);
+        znc_out = uniform((float)sqrt(fmax(e2, 0.0)) * 1.0000005f);
+    }
+    // sum T I = y' / scale + c sum T  (block spectra of the centred stream, pattern spectra scaled: module header)
+    const float tU = uniform((float)(tc.tU - 2.0 * (double)tc.c_sum_t));
+    const float m2s = uniform(-2.0f * tc.inv_scale);
+    const float inv_s = uniform(tc.inv_scale);
+    const float cst = uniform(tc.c_sum_t);
     const float inv_tnorm = uniform(CC ? tc.inv_tnorm_c : tc.inv_tnorm);
     const float tmean = uniform(tc.tmean);
     const float neg_inv_m = uniform(-tc.inv_m);
@@ -683,11 +747,12 @@ __device__ __forceinline__ void score_pair(const IfftArgs& a, cpx (&v)[sushi_fft
                 const int pos = tid + FT * r + half * FH;
                 const bool carry = FT * (r % RPB) >= carry_from;
                 const float wU = (ub0[half][blk] + (carry ? dub[half][blk] : 0.f)) + (rb[q] - ra[q]);   // sum I^2
-                const float corr = half ? v[r].y : v[r].x;
+                const float yv = half ? v[r].y : v[r].x;
                 float score, rs;
                 bool certain;
                 if (CC) {
                     const float wS = (us0[half][blk] + (carry ? dus[half][blk] : 0.f)) + (sb_[q] - sa[q]);   // sum I
+                    const float corr = __builtin_fmaf(yv, inv_s, cst);               // sum T I
                     const float num = __builtin_fmaf(-wS, tmean, corr);              // sum T I - sum I * mean T
                     const float d2 = __builtin_fmaf(wS * neg_inv_m, wS, wU);         // sum I^2 - (sum I)^2 / M
                     certain = d2 > tau;
@@ -695,7 +760,7 @@ __device__ __forceinline__ void score_pair(const IfftArgs& a, cpx (&v)[sushi_fft
                     const float cc = __builtin_amdgcn_fmed3f(num * rs * inv_tnorm, -1.0f, 1.0f);
                     score = certain ? 1.0f - cc : UNCERTAIN;
                 } else {
-                    const float num = (tU + wU) - 2.0f * corr;                       // sum (T - I)^2
+                    const float num = __builtin_fmaf(yv, m2s, tU + wU);              // sum (T - I)^2 = sum T^2 + sum I^2 - 2 sum T I
                     rs = __builtin_amdgcn_rsqf(wU);
                     score = num * rs * inv_tnorm;                                    // ~1 ulp: this stage only ranks
                     score = __builtin_amdgcn_fmed3f(score, 0.0f, 1.0f);              // both clamps (keys need score >= 0)
@@ -736,20 +801,56 @@ __device__ __forceinline__ void score_pair(const IfftArgs& a, cpx (&v)[sushi_fft
 //           16 * eps * |Z|^2 / (|T| * |window|)
 // METHOD 1: numerator error / (|T_c| |W_c|) + the relative error of 1 / sqrt(variance sum) (the score is <= 1 in size)
 template <int METHOD>
-__device__ __forceinline__ float pair_error_model(float zn, float max_rs, const TemplConsts& tc) {
+__device__ __forceinline__ float pair_error_model(float zn, float zn_c, float max_rs, const TemplConsts& tc, float q2,
+                                                  float inv_scale) {
     const float eps = 5.9604645e-8f;                             // 2^-24
+    // quantisation of the Y row: every stored half is off by <= 2^-11 of its size (round to nearest), independently; the
+    // inverse transform sums N of them: variance (2^-22 / 3) * sum |Y(f)|^2 (+ the subnormal floor), Y_KQ deviations
+    const float sigma_y = sqrtf(q2 * (1.0f / 3.0f) * 2.3841858e-7f + (float)FN * 1.2e-15f) * inv_scale;   // 2^-22 / 3: (2^-11)^2, uniform
     if (METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED) {
         const float ism = sqrtf(tc.inv_m);
-        return eps * max_rs * zn * (tc.tnorm * tc.inv_tnorm_c * ccoeff_kn(ism) + ccoeff_cd(ism) * zn * max_rs);
+        const float z = fmaxf(zn, zn_c);
+        return eps * max_rs * z * (tc.tnorm * tc.inv_tnorm_c * ccoeff_kn(ism) + ccoeff_cd(ism) * z * max_rs) +
+               Y_KQ * sigma_y * max_rs * tc.inv_tnorm_c;
     }
-    return eps * max_rs * zn * (2.0f * FFT_KE + 16.0f * zn * tc.inv_tnorm);
+    return eps * max_rs * (2.0f * FFT_KE * zn_c + 16.0f * zn * zn * tc.inv_tnorm) + 2.0f * Y_KQ * sigma_y * max_rs * tc.inv_tnorm;
 }
+
+// sum over the workgroup of a per-thread value, the same in ifft_kernel and collect_kernel whatever the order the waves
+// arrive in: 16 x the largest wave sum (an upper bound, and waves hold similar shares of a row's energy)
+// Wave reductions on the VALU's cross-lane paths (DPP inside rows of 16 lanes, four readlanes across the rows): __shfl_*
+// goes through ds_bpermute_b32 and needs an address register per step, which ifft_kernel does not have to spare.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <class Op>
+__device__ __forceinline__ float row_reduce_f32(float v, Op op) {          // every lane ends with its row's result
+    v = op(v, dpp_f32<0xB1>(v));                                 // quad_perm [1,0,3,2]
+    v = op(v, dpp_f32<0x4E>(v));                                 // quad_perm [2,3,0,1]
+    v = op(v, dpp_f32<0x141>(v));                                // row_half_mirror
+    v = op(v, dpp_f32<0x140>(v));                                // row_mirror
+    return v;
+}
+template <class Op>
+__device__ __forceinline__ float wave_reduce_f32(float v, Op op) {         // wave-uniform result
+    v = row_reduce_f32(v, op);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return op(op(r0, r1), op(r2, r3));
+}
+__device__ __forceinline__ float wave_sum_f32(float v) { return wave_reduce_f32(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ float wave_min_f32(float v) { return wave_reduce_f32(v, [](float a, float b) { return fminf(a, b); }); }
+__device__ __forceinline__ float wave_max_f32(float v) { return wave_reduce_f32(v, [](float a, float b) { return fmaxf(a, b); }); }
 
 template <int METHOD>
 __global__ __launch_bounds__(FT, 8)
 void ifft_kernel(IfftArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     __shared__ unsigned red_min, red_rs;        // float bits (both >= 0: unsigned order == float order)
+    __shared__ float red_q[FT / 64];            // per wave: energy of its share of the Y row
     __shared__ int ccnt, unc_any;
     const int tid = threadIdx.x;
     // which pair: by default the workgroup index; with a schedule the pairs that read the same region of the
@@ -757,9 +858,13 @@ void ifft_kernel(IfftArgs a) {
     // XCD's L2 once instead of once per search
     const int pr = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     cpx v[sushi_fft::PER];
-    load_y(v, a.y + (size_t)pr * FN, tid);                             // in flight while the descriptors below arrive
+    const float q2 = load_y(v, a.y + (size_t)pr * (FN / 2), tid);      // in flight while the descriptors below arrive
     const sushi_fft::WTwiddles tw = sushi_fft::load_wtwiddles<1>(tid, twiddles());
     const int lane = tid & 63;
+    {
+        const float qw = wave_sum_f32(q2);
+        if (lane == 0) red_q[tid >> 6] = qw;                           // read after the barriers inside the transform
+    }
     const int k = __builtin_amdgcn_readfirstlane(a.pairmap[pr]);       // wave-uniform: everything derived from it is scalar
     const SearchDesc sd = a.searches[k];
     const int i = a.sub_first_pair + pr - sd.first_pair;
@@ -775,16 +880,11 @@ void ifft_kernel(IfftArgs a) {
     if (tid == 0) { ccnt = 0; unc_any = 0; red_min = 0x7f800000u; red_rs = 0u; }   // read after the barriers inside the transform
     PairScores ps;
     int plo, phi;
-    float zn;
-    score_pair<METHOD>(a, v, sd, tc, lay.pair0 + i, lds, tid, tw, ps, plo, phi, zn);
+    float zn, zn_c;
+    score_pair<METHOD>(a, v, sd, tc, lay.pair0 + i, lds, tid, tw, ps, plo, phi, zn, zn_c);
     // minimum of the pair and the largest 1/|window| (error bound): 32-bit wave reductions, then one LDS atomic each per
     // wave and ONE barrier -- the workgroup's tail is serial time on a CU that holds two workgroups
-    float wmin = ps.best, wrs = ps.max_rs;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        wmin = fminf(wmin, __shfl_down(wmin, d, 64));
-        wrs = fmaxf(wrs, __shfl_down(wrs, d, 64));
-    }
+    const float wmin = wave_min_f32(ps.best), wrs = wave_max_f32(ps.max_rs);
     if (lane == 0) {
         atomicMin(&red_min, __float_as_uint(wmin));                    // scores are >= 0 or +inf
         atomicMax(&red_rs, __float_as_uint(wrs));
@@ -793,7 +893,9 @@ void ifft_kernel(IfftArgs a) {
     __syncthreads();
     const float lmin_s = __uint_as_float(red_min), rs_max = __uint_as_float(red_rs);
     const bool have_min = lmin_s < __builtin_inff();
-    const float e_model = pair_error_model<METHOD>(zn, rs_max, tc);
+    static_assert(FT / 64 == 16, "one row of lanes reads the sixteen wave sums");
+    const float qmax = row_reduce_f32(red_q[lane & 15], [](float a, float b) { return fmaxf(a, b); });
+    const float e_model = pair_error_model<METHOD>(zn, zn_c, rs_max, tc, (float)(FT / 64) * qmax, tc.inv_scale);
     const float e_pair = fmaxf(0.5f * a.delta, e_model);
     // positions leave this kernel relative to the search's window: p = (pair's first sample + pos) - win_start
     const int64_t shift = (lay.pair0 + i) * (int64_t)FFT_STEP * FFT_SEG - sd.win_start;
@@ -850,7 +952,7 @@ template <int METHOD>
 __global__ __launch_bounds__(FT, 8)
 void collect_kernel(IfftArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    __shared__ float redr[FT / 64];
+    __shared__ float redr[FT / 64], redq[FT / 64];
     __shared__ int tcnt[TILES_PER_PAIR], toff[TILES_PER_PAIR], tfill[TILES_PER_PAIR];
     const int n_flagged = *a.sub_flagged;
     if (n_flagged == 0) return;
@@ -878,17 +980,20 @@ void collect_kernel(IfftArgs a) {
                 PairScores ps;
                 float zn;
                 cpx v[sushi_fft::PER];
-                load_y(v, a.y + (size_t)pr * FN, tid);
-                score_pair<METHOD>(a, v, sd, tc, lay.pair0 + i, lds, tid, tw, ps, plo, phi, zn);
+                const float q2 = load_y(v, a.y + (size_t)pr * (FN / 2), tid);
+                const float qw = wave_sum_f32(q2);
+                float zn_c;
+                score_pair<METHOD>(a, v, sd, tc, lay.pair0 + i, lds, tid, tw, ps, plo, phi, zn, zn_c);
                 float wrs = ps.max_rs;
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) wrs = fmaxf(wrs, __shfl_down(wrs, d, 64));
-                if (lane == 0) redr[wave] = wrs;
+                if (lane == 0) { redr[wave] = wrs; redq[wave] = qw; }
                 __syncthreads();
-                float rs_max = redr[0];
+                float rs_max = redr[0], qmax = redq[0];
 #pragma unroll
-                for (int ww = 1; ww < FT / 64; ++ww) rs_max = fmaxf(rs_max, redr[ww]);
-                const float e_pair = fmaxf(0.5f * a.delta, pair_error_model<METHOD>(zn, rs_max, tc));
+                for (int ww = 1; ww < FT / 64; ++ww) { rs_max = fmaxf(rs_max, redr[ww]); qmax = fmaxf(qmax, redq[ww]); }
+                const float e_pair = fmaxf(0.5f * a.delta,
+                                           pair_error_model<METHOD>(zn, zn_c, rs_max, tc, (float)(FT / 64) * qmax, tc.inv_scale));
 #pragma unroll
                 for (int q = 0; q < 2 * HPT; ++q) {
                     const bool c = fmaxf(ps.scores[q] - e_pair, 0.f) <= U;              // invalid positions hold +inf, uncertain ones -1
@@ -973,7 +1078,7 @@ inline WsLayout ws_layout(int64_t pairs, int64_t segs, int64_t searches) {
     WsLayout w;
     size_t o = 0;
     w.tspec = o; o += align_up((size_t)segs * FN * sizeof(cpx), 256);
-    w.y = o; o += align_up((size_t)pairs * FN * sizeof(cpx), 256);
+    w.y = o; o += align_up((size_t)pairs * FN * 2 * sizeof(uint16_t), 256);      // packed halves: 4 bytes per bin
     w.cand = o; o += align_up((size_t)pairs * FFT_ROW * sizeof(unsigned long long), 256);
     w.pairmap = o; o += align_up((size_t)pairs * sizeof(int), 256);
     w.tconst = o; o += align_up((size_t)searches * sizeof(TemplConsts), 256);
@@ -1248,10 +1353,10 @@ int sushi_hip_stream_add_spectra(SushiHipStream* s, void* mem_dev, size_t mem_by
     // one block more than the stream has: its samples are all past the end, so its spectrum is zero
     if (s->dtype == SUSHI_HIP_F32)
         hipLaunchKernelGGL(spectra_kernel<float>, dim3((unsigned)s->blocks + 1), dim3(FT), 0, (hipStream_t)hip_stream,
-                           (const float*)s->raw, s->n, (cpx*)mem_dev);
+                           (const float*)s->raw, s->n, (cpx*)mem_dev, (const double*)s->stats);
     else
         hipLaunchKernelGGL(spectra_kernel<uint8_t>, dim3((unsigned)s->blocks + 1), dim3(FT), 0, (hipStream_t)hip_stream,
-                           (const uint8_t*)s->raw, s->n, (cpx*)mem_dev);
+                           (const uint8_t*)s->raw, s->n, (cpx*)mem_dev, (const double*)s->stats);
     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
     s->spec = mem_dev;
     s->spec_bytes = need;
@@ -1404,7 +1509,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         TspecArgs ta;
         ta.src_raw = src->raw; ta.searches = searches_dev + sbt.a0; ta.n_sub = n_sub; ta.sub_first_seg = sbt.first_seg;
         ta.tspec = tspec; ta.sub_first_pair = sbt.first_pair; ta.pairmap = pairmap; ta.tconst = tconst;
-        ta.src_s1 = src->s1; ta.src_s2 = src->s2; ta.centre = r.centre;
+        ta.src_s1 = src->s1; ta.src_s2 = src->s2; ta.centre = r.centre; ta.dst_stats = dst->stats;
         if (src->dtype == SUSHI_HIP_F32) hipLaunchKernelGGL(tspec_kernel<float>, dim3((unsigned)sbt.segs), dim3(FT), 0, st, ta);
         else hipLaunchKernelGGL(tspec_kernel<uint8_t>, dim3((unsigned)sbt.segs), dim3(FT), 0, st, ta);
         if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
@@ -1414,7 +1519,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         {
             MacArgs ma;
             ma.spec = (const float4*)dst->spec; ma.spec_blocks = dst->blocks; ma.tspec = (const float4*)tspec;
-            ma.y = (float4*)y; ma.searches = searches_dev + sbt.a0; ma.sub_first_seg = sbt.first_seg;
+            ma.y = (uint2*)y; ma.searches = searches_dev + sbt.a0; ma.sub_first_seg = sbt.first_seg;
             ma.sub_first_pair = sbt.first_pair;
             ma.dummy = (float4*)(wsp + wl.dummy);
             for (int kern = 0; kern < 2; ++kern) {
@@ -1436,7 +1541,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             return SUSHI_HIP_ELAUNCH;
         IfftArgs ia;
         memset(&ia, 0, sizeof(ia));
-        ia.y = y; ia.searches = searches_dev + sbt.a0; ia.n_sub = n_sub; ia.first_search = sbt.a0;
+        ia.y = (const uint2*)y; ia.dst_stats = dst->stats; ia.searches = searches_dev + sbt.a0; ia.n_sub = n_sub; ia.first_search = sbt.a0;
         ia.sub_first_pair = sbt.first_pair; ia.dst_len = dst->n; ia.delta = (float)delta; ia.cand = cand; ia.gkeys = gkeys;
         ia.pairmap = pairmap; ia.tconst = tconst; ia.order = order + sbt.first_pair;
         ia.urel = dst->urel; ia.nb = dst->blocks; ia.ubase = dst->base;

@@ -712,6 +712,34 @@ void final_scan_kernel(const T* __restrict__ raw, int64_t n, const double* __res
     }
 }
 
+// What the FFT path needs to know about a stream as a whole (sushi_fft.hip, "packed halves"): the constant its block
+// spectra are centred by -- the stream's own mean, as a float: any constant is exact (sum T I = sum T (I - c) + c sum T),
+// the mean keeps DC out of the products whatever level the data sits at -- and the largest centred energy of FFT_STEP + 1
+// consecutive blocks (what one block pair's transform can hold at most: the scale of the packed products is derived
+// from it).  One workgroup; bs2 / bs1 are the scanned block bases of sum x^2 / sum x.
+__global__ __launch_bounds__(1024)
+void fft_stats_kernel(const double* __restrict__ bs2, const double* __restrict__ bs1, int nb, int64_t n, double* __restrict__ stats) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x;
+    const double c = (double)(float)(bs1[nb] / (double)n);
+    double emax = 0.0;
+    for (int j = tid; j < nb; j += 1024) {
+        const int je = min(j + FFT_STEP + 1, nb);
+        const int64_t lo = (int64_t)j * PB, hi = min((int64_t)je * PB, n);
+        const double e = (bs2[je] - bs2[j]) - 2.0 * c * (bs1[je] - bs1[j]) + c * c * (double)(hi - lo);
+        emax = e > emax ? e : emax;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_down(emax, d, 64); emax = o > emax ? o : emax; }
+    if ((tid & 63) == 0) red[tid >> 6] = emax;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) emax = red[w] > emax ? red[w] : emax;
+        stats[0] = emax;
+        stats[1] = c;
+    }
+}
+
 inline int launch_ok() { return hipGetLastError() == hipSuccess ? SUSHI_HIP_OK : SUSHI_HIP_ELAUNCH; }
 
 struct Variant { int waves, nb; };
@@ -788,7 +816,7 @@ StreamLayout stream_layout(int64_t n, int searchable) {
     l.s2 = o; o += align_up((size_t)(n + 1) * sizeof(double), 256);
     l.urel = o; o += align_up((size_t)(n + 1) * sizeof(float), 256);
     l.srel = o; o += align_up((size_t)(n + 1) * sizeof(float), 256);
-    l.base_bytes = (size_t)(2 * (nb + 1)) * sizeof(double);      // block bases of sum x^2, then of sum x
+    l.base_bytes = (size_t)(2 * (nb + 1) + 2) * sizeof(double);  // block bases of sum x^2, then of sum x, then the FFT path's stats
     l.base = o; o += align_up(l.base_bytes, 256);
     l.spec = o; o += searchable ? align_up(sushi_hip_stream_spectra_bytes(n), 256) : 0;
     l.total = o;
@@ -848,7 +876,7 @@ int sushi_hip_stream_create(const void* raw_dev, int dtype, int64_t n, int searc
     s->raw = raw_dev; s->dtype = dtype; s->n = n;
     s->xc = (float*)(m + l.xc); s->s1 = (double*)(m + l.s1); s->s2 = (double*)(m + l.s2);
     s->urel = (float*)(m + l.urel); s->srel = (float*)(m + l.srel); s->base = (double*)(m + l.base); s->base_bytes = l.base_bytes;
-    s->spec = nullptr; s->spec_bytes = 0; s->blocks = nb;
+    s->spec = nullptr; s->spec_bytes = 0; s->blocks = nb; s->stats = s->base + 2 * (nb + 1);
     hipStream_t st = (hipStream_t)hip_stream;
     double* bs2 = s->base;                       // block bases of sum x^2 (what the FFT path's scoring reads)
     double* bs1 = s->base + (nb + 1);            // block bases of sum x
@@ -870,6 +898,10 @@ int sushi_hip_stream_create(const void* raw_dev, int dtype, int64_t n, int searc
         else
             hipLaunchKernelGGL(final_scan_kernel<uint8_t>, dim3(nb), dim3(PB_THREADS), 0, st, (const uint8_t*)raw_dev, n,
                                (const double*)bs1, (const double*)bs2, s->s1, s->s2, s->urel, s->srel);
+        rc = launch_ok();
+    }
+    if (rc == SUSHI_HIP_OK) {
+        hipLaunchKernelGGL(fft_stats_kernel, dim3(1), dim3(1024), 0, st, (const double*)bs2, (const double*)bs1, nb, n, s->stats);
         rc = launch_ok();
     }
     if (rc == SUSHI_HIP_OK && searchable)

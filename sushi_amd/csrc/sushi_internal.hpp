@@ -18,7 +18,8 @@ struct SushiHipStream {
     double* s2;               // [n + 1]  prefix sums of their squares
     float* urel;              // [n + 1]  s2 relative to the block base
     float* srel;              // [n + 1]  s1 relative to the block base (TM_CCOEFF_NORMED on the FFT path)
-    double* base;             // [nb + 1] block bases of s2, then [nb + 1] block bases of s1
+    double* base;             // [nb + 1] block bases of s2, then [nb + 1] block bases of s1, then `stats`
+    double* stats;            // [2] FFT path: largest centred energy of seven consecutive blocks; the centring constant
     size_t base_bytes;
     void* spec;               // [(nb + 1) * N] complex f32 block spectra, or null
     size_t spec_bytes;
