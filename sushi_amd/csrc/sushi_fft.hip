@@ -537,7 +537,7 @@ __device__ __forceinline__ float load_y(cpx (&v)[sushi_fft::PER], const uint2* _
         for (int j = 0; j < 4; ++j) {
             const h2 h = __builtin_bit_cast(h2, w[j]);
             v[4 * u + j] = cpx{(float)h.x, (float)h.y};
-            q2 = __builtin_fmaf(v[4 * u + j].x, v[4 * u + j].x, __builtin_fmaf(v[4 * u + j].y, v[4 * u + j].y, q2));
+            q2 = __builtin_amdgcn_fdot2(h, h, q2, false);                  // |Y(f)|^2 straight from the two halves
         }
     }
     return q2;
@@ -761,11 +761,14 @@ __device__ __forceinline__ void score_pair(const IfftArgs& a, cpx (&v)[sushi_fft
                     score = certain ? 1.0f - cc : UNCERTAIN;
                 } else {
                     const float num = __builtin_fmaf(yv, m2s, tU + wU);              // sum (T - I)^2 = sum T^2 + sum I^2 - 2 sum T I
-                    rs = __builtin_amdgcn_rsqf(wU);
+                    // a window without energy scores 1 (cv2's t = 0 case): clamped to a tiny energy its score is huge before
+                    // the clamp to 1, and its 1/|window| blows the pair's bound up so that every position of the pair goes to
+                    // the exact stages -- right, and one v_max instead of a compare and two selects per position (a pattern
+                    // without energy, where num can be 0 as well, is handled before the loop)
+                    rs = __builtin_amdgcn_rsqf(fmaxf(wU, 1e-30f));
                     score = num * rs * inv_tnorm;                                    // ~1 ulp: this stage only ranks
                     score = __builtin_amdgcn_fmed3f(score, 0.0f, 1.0f);              // both clamps (keys need score >= 0)
-                    certain = wU > 0.f;                                              // (has energy)
-                    score = certain ? score : 1.0f;
+                    certain = true;
                 }
                 bool valid = true;
                 if (!INTERIOR) {
@@ -791,6 +794,14 @@ __device__ __forceinline__ void score_pair(const IfftArgs& a, cpx (&v)[sushi_fft
         }
     };
     if (interior) score_all(std::true_type()); else score_all(std::false_type());
+    if (!CC && !(tc.tU > 0.0)) {
+        // a pattern of zeros: cv2's result is all ones (t = 0 everywhere), while num * rs * (1 / 0) above is NaN where the window
+        // has no energy either
+#pragma unroll
+        for (int q = 0; q < 2 * HPT; ++q) ps.scores[q] = ps.scores[q] < __builtin_inff() || ps.scores[q] != ps.scores[q] ? 1.0f : ps.scores[q];
+        best_s = 1.0f;
+        max_rs = fmaxf(max_rs, 1e15f);
+    }
     ps.best = best_s;
     ps.max_rs = max_rs;
     ps.any_uncertain = any_unc;
