@@ -1,0 +1,46 @@
+# Round-3 evidence (profiles/r03/): PMC FETCH / WRITE passes first (so that the bench lines carry roofline.traffic), kernel
+# trace, the bench lines of every workload, the whole GPU suite, smoke, per-call latency.  Every command under its own timeout.
+set -x
+O=gpurun_out/r03final
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export SUSHI_BENCH_CACHE=/tmp/sushi_bench_cache
+B="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --cpu-sample 2"
+timeout 300 $B > $O/warm.json 2> $O/warm.err            # builds the stream cache
+rm -rf gpurun_out/prof_*
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -o kt -- $B > $O/kt.log 2>&1
+timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -o fetch -- $B > $O/fetch.log 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/prof_write -o write -- $B > $O/write.log 2>&1
+cp gpurun_out/prof_kt/kt_kernel_stats.csv $O/cfg2_kernel_stats.csv
+python tools/summarize_pmc.py $O/cfg2_pmc_summary.csv $(find gpurun_out/prof_fetch gpurun_out/prof_write -name '*counter_collection.csv')
+python tools/make_pmc_traffic.py $O/cfg2_pmc_summary.csv profiles/pmc_traffic.json "config2/fft/float32/3000/w120/m120/n1" "$COMMIT" > /dev/null
+# configs[4] counters
+B4="python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline --cpu-sample 2"
+timeout 600 $B4 > $O/warm4.json 2> $O/warm4.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof4_kt -o kt -- $B4 > $O/kt4.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof4_fetch -o fetch -- $B4 > $O/fetch4.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/prof4_write -o write -- $B4 > $O/write4.log 2>&1
+cp gpurun_out/prof4_kt/kt_kernel_stats.csv $O/cfg4_kernel_stats.csv
+python tools/summarize_pmc.py $O/cfg4_pmc_summary.csv $(find gpurun_out/prof4_fetch gpurun_out/prof4_write -name '*counter_collection.csv')
+python tools/make_pmc_traffic.py $O/cfg4_pmc_summary.csv profiles/pmc_traffic.json "config4/fft/float32/5000/w120/m240/n1" "$COMMIT" > /dev/null
+cp profiles/pmc_traffic.json $O/pmc_traffic.json
+# bench lines
+timeout 400 python bench.py --steps 20 --warmup 5 > $O/bench_cfg2_n1.json 2> $O/bench_cfg2_n1.err; head -c 300 $O/bench_cfg2_n1.json; echo
+timeout 300 python bench.py --steps 10 --warmup 3 --sample-type uint8 > $O/bench_cfg2_u8_n1.json 2> $O/e1.err
+timeout 300 python bench.py --steps 10 --warmup 3 --hard-frac 0.05 > $O/bench_cfg2_hard_n1.json 2> $O/e2.err
+timeout 300 python bench.py --steps 10 --warmup 3 --method ccoeff_normed > $O/bench_cfg2_ccoeff_n1.json 2> $O/e3.err
+timeout 300 python bench.py --config 1 --steps 20 --warmup 5 > $O/bench_cfg1_n1.json 2> $O/e4.err
+timeout 600 python bench.py --config 4 --steps 5 --warmup 2 > $O/bench_cfg4_n1.json 2> $O/e5.err
+timeout 300 python bench.py --path direct --steps 1 --warmup 0 --no-cpu-baseline --cpu-sample 64 > $O/bench_cfg2_direct_n1.json 2> $O/e6.err
+timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.log
+timeout 300 python tools/latency.py > $O/latency.json 2> $O/latency.err; tail -3 $O/latency.json
+timeout 60 python tools/kernel_resources.py sushi_fft > $O/kernel_resources_fft.txt 2>&1
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/r03final/bench_*.json")):
+    try:
+        d=json.load(open(f)); r=d["roofline"]; p=d["parity"]
+        print(f.split("/")[-1], round(d["value"]), round(d["ms_per_step"],2), r.get("stage_ms"), "frac", round(r["frac"],3), "traffic", r.get("traffic"), "oracle", p["oracle_sample_searches"], "idx_err", p.get("max_idx_err_vs_oracle_sample"), "cpu", d["cpu_baseline"] and round(d["cpu_baseline"]["value"],1))
+    except Exception as e: print(f, "ERR", e)
+PY
