@@ -478,6 +478,7 @@ struct IfftArgs {
     int64_t dst_len;
     float delta;
     unsigned long long* cand;         // [pairs of the sub-batch][FFT_ROW]
+    float* pair_lb;                   // [pairs of the sub-batch] smallest lower bound (score - e) of the pair: what refine_kernel scans
     unsigned long long* gkeys;        // [all searches] running minimum of (f32 score + error bound)
     const int* pairmap;               // [pairs of the sub-batch] -> search index inside the sub-batch
     const int* order;                 // [pairs of the sub-batch] workgroup -> pair (L2-friendly schedule) or NULL
@@ -885,7 +886,7 @@ void ifft_kernel(IfftArgs a) {
     unsigned long long* __restrict__ cout = a.cand + (size_t)pr * FFT_ROW;
     if (METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED && tc.flat) {
         // a pattern without variance: cv2's result is all ones (refine_kernel answers position 0); nothing to rank
-        if (tid == 0) cout[FFT_CAND + 1] = 0ull;
+        if (tid == 0) { cout[FFT_CAND + 1] = 0ull; a.pair_lb[pr] = __builtin_inff(); }
         return;
     }
     if (tid == 0) { ccnt = 0; unc_any = 0; red_min = 0x7f800000u; red_rs = 0u; }   // read after the barriers inside the transform
@@ -910,7 +911,13 @@ void ifft_kernel(IfftArgs a) {
     const float e_pair = fmaxf(0.5f * a.delta, e_model);
     // positions leave this kernel relative to the search's window: p = (pair's first sample + pos) - win_start
     const int64_t shift = (lay.pair0 + i) * (int64_t)FFT_STEP * FFT_SEG - sd.win_start;
-    if (tid == 0) cout[FFT_CAND + 1] = ((unsigned long long)__float_as_uint(e_model) << 32) | __float_as_uint(e_pair);
+    if (tid == 0) {
+        cout[FFT_CAND + 1] = ((unsigned long long)__float_as_uint(e_model) << 32) | __float_as_uint(e_pair);
+        // the smallest lower bound among the pair's positions: refine_kernel reads this one float per pair and opens the row
+        // only of pairs that can hold the search's extremum (it used to read every row of every pair: 10 KB per search)
+        const bool unc = METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED && unc_any;
+        a.pair_lb[pr] = unc ? 0.f : (have_min ? fmaxf(lmin_s - e_pair, 0.f) : __builtin_inff());
+    }
     // a position can be the search's minimum only if score - e <= (smallest score + e) of the search; inside the
     // pair that is score <= lmin_s + 2 e (refine_kernel applies the search-wide threshold to the stored lower bounds);
     // uncertain positions (METHOD 1) always can
@@ -1084,13 +1091,14 @@ inline int64_t cand_capacity(int64_t pairs) {
 }
 
 // bytes of workspace for one sub-batch of `pairs` block pairs, `segs` pattern segments and `searches` searches
-struct WsLayout { size_t tspec, y, cand, pairmap, tconst, tiles, candbuf, dummy, total; };
+struct WsLayout { size_t tspec, y, cand, pair_lb, pairmap, tconst, tiles, candbuf, dummy, total; };
 inline WsLayout ws_layout(int64_t pairs, int64_t segs, int64_t searches) {
     WsLayout w;
     size_t o = 0;
     w.tspec = o; o += align_up((size_t)segs * FN * sizeof(cpx), 256);
     w.y = o; o += align_up((size_t)pairs * FN * 2 * sizeof(uint16_t), 256);      // packed halves: 4 bytes per bin
     w.cand = o; o += align_up((size_t)pairs * FFT_ROW * sizeof(unsigned long long), 256);
+    w.pair_lb = o; o += align_up((size_t)pairs * sizeof(float), 256);
     w.pairmap = o; o += align_up((size_t)pairs * sizeof(int), 256);
     w.tconst = o; o += align_up((size_t)searches * sizeof(TemplConsts), 256);
     w.tiles = o; o += align_up((size_t)pairs * TILES_PER_PAIR * sizeof(TileDesc), 256);
@@ -1512,6 +1520,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         cpx* y = (cpx*)(wsp + wl.y);
         unsigned long long* cand = (unsigned long long*)(wsp + wl.cand);
         int* pairmap = (int*)(wsp + wl.pairmap);
+        float* pair_lb = (float*)(wsp + wl.pair_lb);
         TemplConsts* tconst = (TemplConsts*)(wsp + wl.tconst);
         TileDesc* tiles = (TileDesc*)(wsp + wl.tiles);
         int32_t* candbuf = (int32_t*)(wsp + wl.candbuf);
@@ -1553,7 +1562,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         IfftArgs ia;
         memset(&ia, 0, sizeof(ia));
         ia.y = (const uint2*)y; ia.dst_stats = dst->stats; ia.searches = searches_dev + sbt.a0; ia.n_sub = n_sub; ia.first_search = sbt.a0;
-        ia.sub_first_pair = sbt.first_pair; ia.dst_len = dst->n; ia.delta = (float)delta; ia.cand = cand; ia.gkeys = gkeys;
+        ia.sub_first_pair = sbt.first_pair; ia.dst_len = dst->n; ia.delta = (float)delta; ia.cand = cand; ia.pair_lb = pair_lb; ia.gkeys = gkeys;
         ia.pairmap = pairmap; ia.tconst = tconst; ia.order = order + sbt.first_pair;
         ia.urel = dst->urel; ia.nb = dst->blocks; ia.ubase = dst->base;
         ia.srel = dst->srel; ia.sbase = dst->base + (dst->blocks + 1);
@@ -1569,7 +1578,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         t0 = prof_begin(pc, st);
         RefineParams rp;
         rp.r = r; rp.searches = searches_dev; rp.first_search = sbt.a0; rp.n_sub = n_sub; rp.sub_first_pair = sbt.first_pair;
-        rp.cand = cand; rp.gkeys = gkeys; rp.keys = keys; rp.flags = flags; rp.flag_list = flag_list;
+        rp.cand = cand; rp.pair_lb = pair_lb; rp.gkeys = gkeys; rp.keys = keys; rp.flags = flags; rp.flag_list = flag_list;
         rp.sub_flagged = sub_flagged; rp.counters = counters; rp.delta = (float)delta; rp.method = b->method;
         int rc = launch_refine(rp, st);
         if (rc != SUSHI_HIP_OK) return rc;

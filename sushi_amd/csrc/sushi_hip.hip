@@ -242,18 +242,49 @@ constexpr int XT = TILE;         // positions per tile
 constexpr int XM = 512;          // pattern samples per chunk of the canonical sum
 static_assert(XT == 1024 && XM % 4 == 0, "exact_tiles_kernel: 256 threads x 4 consecutive positions, steps of 4 samples");
 
+// 16 bytes of a stream at any element boundary as ONE load: a thread walks its own chunk, so neighbouring lanes read 2 KB
+// apart and every load instruction touches 64 different lines whatever its width -- a dwordx4 brings four (sixteen) samples
+// for the price of one (gfx950 global loads need no more than byte alignment; the order of the additions is untouched)
+template <typename T> struct WideLoad;
+template <> struct WideLoad<float> { static constexpr int N = 4; struct __attribute__((packed, aligned(4))) V { float v[4]; }; };
+template <> struct WideLoad<uint8_t> { static constexpr int N = 16; struct __attribute__((packed, aligned(1))) V { uint8_t v[16]; }; };
+
 template <typename T>
 __device__ __forceinline__ double chunk_dot(const T* __restrict__ t, const T* __restrict__ w, int mc) {
+    typedef typename WideLoad<T>::V V;
+    constexpr int N = WideLoad<T>::N;
+    constexpr int K = N >= 16 ? 1 : 2;                   // a step = 16 uint8 / 8 float32 samples
+    constexpr int STEP = K * N;
     double acc = 0.0;
     int m = 0;
-    for (; m + 8 <= mc; m += 8) {                       // eight independent loads in flight, then the additions in order
-        T a[8], b[8];
+    // A thread's chunk is a chain of dependent steps, each waiting for memory that nobody else has touched (neighbouring lanes
+    // read 2 KB apart): the loads of step i + 1 are issued before the additions of step i (the chain was 64 memory round trips
+    // long per chunk and what refine_kernel's time consisted of); the order of the additions is untouched.
+    V a[K], b[K], an[K], bn[K];
+    const int steps = mc / STEP;
+    if (steps > 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { a[j] = t[m + j]; b[j] = w[m + j]; }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc = __builtin_fma((double)a[j], (double)b[j], acc);
+        for (int j = 0; j < K; ++j) {
+            a[j] = *reinterpret_cast<const V*>(t + N * j);
+            b[j] = *reinterpret_cast<const V*>(w + N * j);
+        }
     }
-    for (; m < mc; ++m) acc = __builtin_fma((double)t[m], (double)w[m], acc);
+    for (int i = 0; i < steps; ++i) {
+        const int mn = (i + 1 < steps ? i + 1 : i) * STEP;          // (the last step re-requests itself: unconditional loads)
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            an[j] = *reinterpret_cast<const V*>(t + mn + N * j);
+            bn[j] = *reinterpret_cast<const V*>(w + mn + N * j);
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) acc = __builtin_fma((double)a[j].v[e], (double)b[j].v[e], acc);
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) { a[j] = an[j]; b[j] = bn[j]; }
+    }
+    for (m = steps * STEP; m < mc; ++m) acc = __builtin_fma((double)t[m], (double)w[m], acc);
     return acc;
 }
 
@@ -375,7 +406,7 @@ template <typename T>
 __device__ __forceinline__ void refine_body(const RefineParams& a, const int s_idx, const SearchDesc& sd,
                                             const unsigned long long* list, const int* lpair,
                                             const unsigned long long* rows, const int n, const int audit_k, double* part,
-                                            unsigned long long* rkey, float* rerr, int* violated) {
+                                            unsigned long long* rkey, float* rerr, int* violated, unsigned* wg_ratio) {
     const int tid = threadIdx.x;
     const int M = sd.tmpl_len;
     const int n_chunks = (M + XM - 1) / XM;
@@ -405,11 +436,11 @@ __device__ __forceinline__ void refine_body(const RefineParams& a, const int s_i
         if (k == audit_k) {                                     // a position that was NOT selected: its plain f32 score
             err = fabsf(lb - ranked);
             if (err > e_pair * 1.001f + 1e-7f) *violated = 1;   // the model failed where nobody was looking: every position
-            if (e_model > 0.f) atomicMax(&a.counters->max_ratio_audit_bits, __float_as_uint(err / e_model));
+            if (e_model > 0.f) atomicMax(&wg_ratio[1], __float_as_uint(err / e_model));
         } else if (lb > 0.f) {                                  // the f32 score itself (a bound clamped at 0 lost it)
             err = fabsf((lb + e_pair) - ranked);
             if (err > e_pair * 1.001f + 1e-7f) *violated = 1;
-            if (e_model > 0.f) atomicMax(&a.counters->max_ratio_bits, __float_as_uint(err / e_model));
+            if (e_model > 0.f) atomicMax(&wg_ratio[0], __float_as_uint(err / e_model));
         }
         rerr[k] = err;
     };
@@ -458,26 +489,28 @@ void refine_kernel(RefineParams a) {
     __shared__ float rerr[RCAP + 1];
     __shared__ double part[256];
     __shared__ int cnt, ovf, violated;
+    __shared__ unsigned wg_ratio[2];             // this search's largest error / bound ratios (float bits): candidates, audit
     const int tid = threadIdx.x;
     const int s_idx = a.first_search + blockIdx.x;
     const SearchDesc sd = a.searches[s_idx];
     const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
-    if (tid == 0) { cnt = 0; ovf = 0; violated = 0; }
+    if (tid == 0) { cnt = 0; ovf = 0; violated = 0; wg_ratio[0] = 0u; wg_ratio[1] = 0u; }
     __syncthreads();
     // none: TM_CCOEFF_NORMED with every window uncertain -- then every listed position is a candidate
     const float U = a.gkeys[s_idx] == NO_KEY ? 4.0f : key_score(a.gkeys[s_idx]);
     const unsigned long long* __restrict__ rows = a.cand + (size_t)(sd.first_pair - a.sub_first_pair) * FFT_ROW;
-    const int n_ent = lay.n_pairs * FFT_ROW;
-    for (int e = tid; e < n_ent; e += 256) {
-        const int slot = e % FFT_ROW;
-        if (slot > FFT_CAND) continue;                                         // the pair's error bound / audit position, not candidates
-        const unsigned long long key = rows[e];
-        if (key != NO_KEY && key_score(key) <= U) {
-            if (slot == FFT_CAND) {
-                ovf = 1;                                   // that pair had more candidate positions than slots
-            } else {
-                const int k = atomicAdd(&cnt, 1);
-                if (k < RCAP) { list[k] = key; lpair[k] = e / FFT_ROW; } else ovf = 1;
+    const float* __restrict__ plb = a.pair_lb + (sd.first_pair - a.sub_first_pair);
+    for (int i = tid; i < lay.n_pairs; i += 256) {
+        if (!(plb[i] <= U)) continue;                         // no position of this pair can be the extremum
+        for (int slot = 0; slot <= FFT_CAND; ++slot) {          // (slots behind FFT_CAND: the pair's error bound / audit position)
+            const unsigned long long key = rows[(size_t)i * FFT_ROW + slot];
+            if (key != NO_KEY && key_score(key) <= U) {
+                if (slot == FFT_CAND) {
+                    ovf = 1;                                   // that pair had more candidate positions than slots
+                } else {
+                    const int k = atomicAdd(&cnt, 1);
+                    if (k < RCAP) { list[k] = key; lpair[k] = i; } else ovf = 1;
+                }
             }
         }
     }
@@ -507,11 +540,15 @@ void refine_kernel(RefineParams a) {
             }
         }
         __syncthreads();
-        if (a.r.dtype == SUSHI_HIP_F32) refine_body<float>(a, s_idx, sd, list, lpair, rows, n_all, audit_k, part, rkey, rerr, &violated);
-        else refine_body<uint8_t>(a, s_idx, sd, list, lpair, rows, n_all, audit_k, part, rkey, rerr, &violated);
+        if (a.r.dtype == SUSHI_HIP_F32) refine_body<float>(a, s_idx, sd, list, lpair, rows, n_all, audit_k, part, rkey, rerr, &violated, wg_ratio);
+        else refine_body<uint8_t>(a, s_idx, sd, list, lpair, rows, n_all, audit_k, part, rkey, rerr, &violated, wg_ratio);
         __syncthreads();
     }
     if (tid == 0) {
+        // the run's maxima: one global atomic per search only where it raises the value -- every workgroup hitting the same two
+        // words with an atomic each was most of this kernel's time (same-address atomics serialise in the L2)
+        if (wg_ratio[0] > *(volatile uint32_t*)&a.counters->max_ratio_bits) atomicMax(&a.counters->max_ratio_bits, wg_ratio[0]);
+        if (wg_ratio[1] > *(volatile uint32_t*)&a.counters->max_ratio_audit_bits) atomicMax(&a.counters->max_ratio_audit_bits, wg_ratio[1]);
         if (ovf || violated) {
             // keys[s_idx] stays NO_KEY for exact_tiles_kernel; gkeys[s_idx] keeps the threshold collect_kernel needs
             a.flags[s_idx] = violated ? 2 : 1;

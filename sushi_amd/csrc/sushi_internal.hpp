@@ -82,6 +82,7 @@ struct RefineParams {
     const SearchDesc* searches;       // all searches of the batch
     int first_search, n_sub, sub_first_pair;
     const unsigned long long* cand;   // [pairs of the sub-batch][FFT_ROW]
+    const float* pair_lb;             // [pairs of the sub-batch] smallest lower bound of each pair
     unsigned long long* gkeys;        // [all searches] in: min over pairs of (f32 score + bound); out: |f32 - exact| bits
     unsigned long long* keys;         // [all searches] result keys
     int* flags;                       // [all searches]
