@@ -11,6 +11,8 @@ rm -rf gpurun_out/prof_*
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -o kt -- $B > $O/kt.log 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -o fetch -- $B > $O/fetch.log 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/prof_write -o write -- $B > $O/write.log 2>&1
+timeout 200 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum --kernel-include-regex "ifft_kernel|mac_kernel" --output-format csv -d gpurun_out/prof_tcp -o tcp -- python tools/stage_times.py --steps 2 --tag tcp > $O/tcp.log 2>&1
+python tools/summarize_pmc.py $O/cfg2_tcp_summary.csv $(find gpurun_out/prof_tcp -name '*counter_collection.csv'); cat $O/cfg2_tcp_summary.csv
 cp gpurun_out/prof_kt/kt_kernel_stats.csv $O/cfg2_kernel_stats.csv
 python tools/summarize_pmc.py $O/cfg2_pmc_summary.csv $(find gpurun_out/prof_fetch gpurun_out/prof_write -name '*counter_collection.csv')
 python tools/make_pmc_traffic.py $O/cfg2_pmc_summary.csv profiles/pmc_traffic.json "config2/fft/float32/3000/w120/m120/n1" "$COMMIT" > /dev/null
