@@ -53,7 +53,12 @@ class ShardedSearch(object):
     `make_batch(lo, hi)` must return an object with `.run()` -> (idx, score) device tensors for
     searches [lo, hi) (a `SearchBatch` on the GPU; the CPU tests pass a stand-in).  `device`: where a rank
     WITHOUT searches (more ranks than searches) allocates its empty contribution -- RCCL gathers device
-    tensors only, so it must be this rank's GPU under the nccl backend (None: CPU, for gloo)."""
+    tensors only, so it must be this rank's GPU under the nccl backend (None: CPU, for gloo).
+
+    The gather's buffers are allocated once: a step costs two small copies into the packed block, the one collective,
+    and -- when every rank holds the same number of searches (3000 events on 8 GPUs) -- no kernel at all on the way out
+    (the results are strided views of the gathered buffer); at 375 events per rank a step is 3.5 ms of kernels, and a
+    dozen tiny launches around the collective would be a few per cent of it."""
 
     def __init__(self, n_total, make_batch, group=None, device=None):
         self.n_total = n_total
@@ -63,6 +68,7 @@ class ShardedSearch(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.lo, self.hi = shard_bounds(n_total, self.rank, self.world)
         self.batch = make_batch(self.lo, self.hi) if self.hi > self.lo else None
+        self._packed = self._full = None
 
     def all_bounds(self):
         return [shard_bounds(self.n_total, r, self.world) for r in range(self.world)]
@@ -78,7 +84,23 @@ class ShardedSearch(object):
         """The one collective of the path: everyone's (idx, score) in global search order."""
         if self.world == 1:
             return idx, score
-        return gather_results(idx, score, self.n_total, self.group)
+        pad = max_shard(self.n_total, self.world)
+        if self._packed is None or self._packed.device != idx.device:
+            self._packed = torch.full((pad, 2), -1, dtype=torch.int32, device=idx.device)
+            self._full = torch.empty((self.world * pad, 2), dtype=torch.int32, device=idx.device)
+        n = idx.shape[0]
+        self._packed[:n, 0].copy_(idx)
+        self._packed[:n, 1].copy_(score.view(torch.int32))
+        dist.all_gather_into_tensor(self._full, self._packed, group=self.group)
+        if self.n_total == self.world * pad:                  # equal blocks: the gathered buffer IS the result, in order
+            return self._full[:, 0], self._full[:, 1].view(torch.float32)
+        full = self._full.view(self.world, pad, 2)
+        pieces_i, pieces_s = [], []
+        for r in range(self.world):
+            lo, hi = shard_bounds(self.n_total, r, self.world)
+            pieces_i.append(full[r, :hi - lo, 0])
+            pieces_s.append(full[r, :hi - lo, 1])
+        return torch.cat(pieces_i), torch.cat(pieces_s).view(torch.float32)
 
     def run(self):
         return self.gather(*self.run_local())

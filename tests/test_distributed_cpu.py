@@ -54,6 +54,7 @@ def _worker(rank, world, port, n_total, out_q):
             return torch.tensor(idx, dtype=torch.int32), torch.tensor(np.array(sc, np.float32))
 
     sh = ShardedSearch(n_total, OracleBatch)
+    sh.run()                                           # (twice: the second step reuses the gather's buffers)
     idx, score = sh.run()
     full = OracleBatch(0, n_total).run()
     ok = bool((idx == full[0]).all()) and bool((score.view(torch.int32) == full[1].view(torch.int32)).all())
@@ -63,7 +64,7 @@ def _worker(rank, world, port, n_total, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [7, 1])
+@pytest.mark.parametrize("n_total", [7, 1, 6])      # uneven blocks, a rank without searches, equal blocks (strided views out)
 def test_two_rank_gloo_shard_and_gather(n_total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
