@@ -78,15 +78,17 @@ SUSHI_HIP_API int sushi_hip_device_ok(void);
  *   srel[n+1]  float32 + base1[nb+1] float64: the same for s1 (window sums of TM_CCOEFF_NORMED)
  *   spectra    (searchable streams only; sushi_hip_stream_add_spectra attaches them later)  for every block
  *              j = 0 .. nb-1 the N-point complex DFT, N = sushi_hip_fft_size(), H = N - B, of
- *                  x[jB .. jB+N) + i * x[jB+H .. jB+H+N)         (zeros past the end), bin f at sushi_hip_fft_slot_of_bin(f),
- *              followed by one all-zero block: sushi_hip_stream_spectra_bytes(n) = (nb + 1) * N * 8 bytes.
+ *                  (x - mean)[jB .. jB+N) + i * (x - mean)[jB+H .. jB+H+N)         (zeros past the end)
+ *              as packed halves (float16 re, float16 im: 4 bytes per bin) times one power of two per stream, bin f at
+ *              sushi_hip_fft_slot_of_bin(f), followed by one all-zero block:
+ *              sushi_hip_stream_spectra_bytes(n) = (nb + 1) * N * 4 bytes.
  * A stream that is only a source of patterns does not need spectra. */
 typedef struct SushiHipStream SushiHipStream;
 
 SUSHI_HIP_API int sushi_hip_fft_size(void);      /* N: complex points per transform */
 SUSHI_HIP_API int sushi_hip_fft_block(void);     /* B: samples per block = per pattern segment */
-/* Where bin f (0 <= f < N) of a block spectrum sits inside its N stored complex values: spectra are kept in the order
- * the inverse transform loads them (coalesced 16-byte loads), not in natural order.  -1 for an invalid bin. */
+/* Where bin f (0 <= f < N) of a block spectrum sits inside its N stored complex values (4 bytes each): spectra are kept
+ * in the order the inverse transform loads them (coalesced 16-byte loads), not in natural order.  -1 for an invalid bin. */
 SUSHI_HIP_API int sushi_hip_fft_slot_of_bin(int bin);
 SUSHI_HIP_API double sushi_hip_centre(int dtype);
 SUSHI_HIP_API size_t sushi_hip_stream_bytes(int64_t n, int dtype, int searchable);

@@ -64,22 +64,42 @@ SUSHI_HD cpx cadd(cpx a, cpx b) { return cpx{a.x + b.x, a.y + b.y}; }
 SUSHI_HD cpx csub(cpx a, cpx b) { return cpx{a.x - b.x, a.y - b.y}; }
 SUSHI_HD cpx cmul(cpx a, cpx b) { return cpx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 SUSHI_HD cpx cconj(cpx a) { return cpx{a.x, -a.y}; }
+SUSHI_HD float fmaf_(float a, float b, float c) {
+#ifdef __HIPCC__
+    return __builtin_fmaf(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
 
-// exp(DIR * 2*pi*i * q/32), q = 0..15, as compile-time cases (q is a constant after unrolling)
+// lo = e + w o, hi = e - w o for w = exp(DIR * 2*pi*i * q/32), q = 0..15 a constant after unrolling: the twiddle is folded into
+// the butterfly's own multiply-adds -- six operations for a general root (hi = 2 e - lo) and for the odd multiples of pi/4,
+// four for 1 and +-i, where a multiplication followed by an addition and a subtraction takes eight
 template <int DIR>
-SUSHI_HD cpx mul_root32(cpx a, int q) {
+SUSHI_HD void bfly_root32(const cpx e, const cpx o, int q, cpx& lo, cpx& hi) {
     const float H = 0.70710678118654752440f;
     const float C[9] = {1.0f, 0.98078528040323044913f, 0.92387953251128673848f, 0.83146961230254523708f, H,
                         0.55557023301960222474f, 0.38268343236508978178f, 0.19509032201612826785f, 0.0f};
     const float s = (float)DIR;
     switch (q) {
-        case 0: return a;
-        case 4: return cpx{H * (a.x - s * a.y), H * (a.y + s * a.x)};
-        case 8: return cpx{-s * a.y, s * a.x};
-        case 12: return cpx{-H * (a.x + s * a.y), H * (s * a.x - a.y)};
-        default:
+        case 0: lo = cadd(e, o); hi = csub(e, o); return;
+        case 8: lo = cpx{e.x - s * o.y, e.y + s * o.x}; hi = cpx{e.x + s * o.y, e.y - s * o.x}; return;
+        case 4: {
+            const float p = o.x - s * o.y, r = o.y + s * o.x;
+            lo = cpx{fmaf_(H, p, e.x), fmaf_(H, r, e.y)}; hi = cpx{fmaf_(-H, p, e.x), fmaf_(-H, r, e.y)};
+            return;
+        }
+        case 12: {
+            const float p = o.x + s * o.y, r = s * o.x - o.y;
+            lo = cpx{fmaf_(-H, p, e.x), fmaf_(H, r, e.y)}; hi = cpx{fmaf_(H, p, e.x), fmaf_(-H, r, e.y)};
+            return;
+        }
+        default: {
             // cos(2 pi q / 32) = C[q] (q <= 8), -C[16 - q] (q > 8); sin = C[8 - q] (q <= 8), C[q - 8] (q > 8)
-            return cmul(a, cpx{q <= 8 ? C[q] : -C[16 - q], s * (q <= 8 ? C[8 - q] : C[q - 8])});
+            const float c = q <= 8 ? C[q] : -C[16 - q], sn = s * (q <= 8 ? C[8 - q] : C[q - 8]);
+            lo = cpx{fmaf_(-sn, o.y, fmaf_(c, o.x, e.x)), fmaf_(sn, o.x, fmaf_(c, o.y, e.y))};
+            hi = cpx{fmaf_(2.0f, e.x, -lo.x), fmaf_(2.0f, e.y, -lo.y)};
+        }
     }
 }
 
@@ -93,11 +113,7 @@ struct Dft {
         Dft<R / 2, DIR>::run(e);
         Dft<R / 2, DIR>::run(o);
 #pragma unroll
-        for (int t = 0; t < R / 2; ++t) {
-            const cpx ow = mul_root32<DIR>(o[t], t * (32 / R));
-            v[t] = cadd(e[t], ow);
-            v[t + R / 2] = csub(e[t], ow);
-        }
+        for (int t = 0; t < R / 2; ++t) bfly_root32<DIR>(e[t], o[t], t * (32 / R), v[t], v[t + R / 2]);
     }
 };
 template <int DIR>
@@ -228,10 +244,10 @@ constexpr int WN = 16384, WNT = 1024;
 constexpr int WROW = 18;                       // floats per padded run of 16
 constexpr int W_LDS_FLOATS = WROW * 1024;      // 72 KB: the workgroup exchange; a wave's row exchange uses floats [1152 w, 1152 w + 1152)
 
-// float4 index, inside a stored spectrum of N complex values, of the register pair (2t, 2t+1) of thread `tid`
-// (registers 4u .. 4u+3 of a thread are neighbours in a stored row, bin pairs t = 2u and 2u + 1: a product row Y, kept as
-// packed halves, is then loaded 16 bytes = four registers at a time)
-SUSHI_HD int wslot_float4(int tid, int t) { return (((((tid >> 6) * 4 + (t >> 1)) << 6) + (tid & 63)) << 1) + (t & 1); }
+// index of the 4-bin entry, inside a stored spectrum of N complex values, that holds registers 4u .. 4u+3 of thread `tid`
+// (spectra are stored as packed halves: an entry is 16 bytes, one load brings four registers, a wave's load instruction
+// one contiguous KiB)
+SUSHI_HD int wslot_uint4(int tid, int u) { return (((tid >> 6) * 4 + u) << 6) + (tid & 63); }
 // the frequency bin a thread's register d1 holds when it loads a stored spectrum
 SUSHI_HD int wbin(int tid, int d1) { return (tid >> 6) + 1024 * d1 + 64 * (tid & 15) + 16 * ((tid >> 4) & 3); }
 // complex index, inside a stored spectrum, of bin f

@@ -63,26 +63,44 @@ static_assert(FH % FT == 0 && FFT_SEG % FT == 0 && HPT == FFT_VB * RPB, "positio
 static_assert(HPT <= sushi_fft::PER, "a thread's valid outputs are a prefix of its transform outputs");
 constexpr int LDS_FLOATS = sushi_fft::lds_floats<FFT_LOGN>();
 
-// ---- the products Y leave mac_kernel as packed halves (half the bytes of the step's dominant traffic) -------------
+// ---- block spectra, pattern spectra and their products Y are all kept as packed halves -----------------------------
+// (half the bytes of everything the step moves between kernels, and two multiply-adds per v_dot2_f32_f16 in mac_kernel)
 // Two things make 11 bits enough for a stage that only ranks:
-//  * block spectra are of the CENTRED destination samples (x - c, c = 0.5 | 128), patterns stay as they are:
+//  * block spectra are of the CENTRED destination samples (x - c), patterns stay as they are:
 //        y'[p] = sum_m T[m] (I[p+m] - c) = sum T I - c sum T
 //    -- the correction is one constant per search -- and Y then carries no product of two DC terms: its energy, and with
 //    it the quantisation noise of every position, is that of pattern x centred audio instead of ~M/4 at every position;
 //  * the noise is modelled per pair from the energy of the Y row actually loaded (Parseval), added to the pair's error
 //    bound, and checked like the rest of the bound (candidates and one audited non-candidate per search, refine_kernel).
+//    Rounding the two factors to halves before they are multiplied perturbs a product Tt_s(f) Z_j(f) by the same relative
+//    2^-11 per factor as rounding the sum does afterwards: with the terms of a bin's sum taken as independent that is two
+//    more times the variance of the stored row's own rounding (pair_error_model).
 // The constant c is the stream's own mean (any constant is exact; the mean keeps DC out whatever level the data sits at).
-// Pattern spectra carry a power-of-two scale per search so that no product can overflow a half whatever the magnitude of
-// the data: |Y(f)| <= sum_s |Tt_s(f)| * max_j |Z_j(f)| <= (64 sqrt(n_seg) |T| / N) * (sqrt(7 * 4096) sqrt(E7)), E7 = the
-// largest centred energy of FFT_STEP + 1 consecutive blocks of the stream (SushiHipStream.stats); typical products sit
-// ~sqrt(N) below that bound, twenty binary orders above the smallest normal half.
-__device__ __forceinline__ float y_scale_for(double tnorm, int n_seg, double e7) {
-    const double bound = (64.0 * sqrt((double)n_seg) * tnorm / (double)FN) * (169.33 * sqrt(e7));
+// Power-of-two scales keep every stored half inside the format whatever the magnitude of the data, and away from its
+// subnormals: block spectra by the stream (|Z_j(f)| <= sqrt(2 N E7), E7 = the largest centred energy of FFT_STEP + 1
+// consecutive blocks, SushiHipStream.stats), pattern spectra by the pattern (|Tt_s(f)| <= 64 |T| / N), and the float32
+// sums of their products are brought to the scale of Y when they are stored:
+//   |Y(f)| <= sum_s |Tt_s(f)| * max_j |Z_j(f)| <= (64 sqrt(n_seg) |T| / N) * (sqrt(7 * 4096) sqrt(E7));
+// typical values sit ~sqrt(N) below these bounds, twenty binary orders above the smallest normal half.
+__device__ __forceinline__ float pow2_under(double target, double bound) {
     if (!(bound > 0.0)) return 1.0f;
-    int k = (int)floor(log2(32768.0 / bound));
+    int k = (int)floor(log2(target / bound));
     k = k < -60 ? -60 : (k > 60 ? 60 : k);
     return (float)ldexp(1.0, k);
 }
+__device__ __forceinline__ float y_scale_for(double tnorm, int n_seg, double e7) {
+    return pow2_under(32768.0, (64.0 * sqrt((double)n_seg) * tnorm / (double)FN) * (169.33 * sqrt(e7)));
+}
+__device__ __forceinline__ float z_scale_for(double e7) { return pow2_under(32768.0, 181.02 * sqrt(e7)); }
+__device__ __forceinline__ float t_scale_for(double tnorm) { return pow2_under(8192.0, 64.0 * tnorm / (double)FN); }
+// one complex number as a packed half pair (re | im << 16), round to nearest even, never infinite
+__device__ __forceinline__ unsigned pack_h2(float re, float im) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 q = {(_Float16)__builtin_amdgcn_fmed3f(re, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(im, -65504.f, 65504.f)};
+    return __builtin_bit_cast(unsigned, q);
+}
+constexpr int ROW_BYTES = FN * 4;              // a stored spectrum: one 32-bit word per bin
+constexpr int ROWE = FN / sushi_mac::BINS;     // ... as 16-byte entries (four bins: what a lane of mac_kernel owns)
 constexpr float Y_KQ = 8.0f;                  // the quantisation term of a pair's bound, in standard deviations
 static_assert(FFT_LOGN == 14 && sushi_fft::W_LDS_FLOATS <= LDS_FLOATS && FT == sushi_fft::WNT, "the wave plan is the 16384-point inverse");
 
@@ -125,8 +143,9 @@ __device__ __forceinline__ const cpx* twiddles() { return reinterpret_cast<const
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(FT)
-void spectra_kernel(const T* __restrict__ raw, int64_t n, cpx* __restrict__ spec, const double* __restrict__ stats) {
+void spectra_kernel(const T* __restrict__ raw, int64_t n, uint32_t* __restrict__ spec, const double* __restrict__ stats) {
     const float centre = (float)stats[1];
+    const float sz = z_scale_for(stats[0]);
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     const int tid = threadIdx.x;
     const sushi_fft::Twiddles tw = sushi_fft::load_twiddles<FFT_LOGN, -1>(tid, twiddles());
@@ -144,10 +163,11 @@ void spectra_kernel(const T* __restrict__ raw, int64_t n, cpx* __restrict__ spec
     }
     sushi_fft::fft_split<FFT_LOGN, -1>(v, tid, lds, tw);
     to_load_order(v, tid, lds);
-    float4* __restrict__ out = reinterpret_cast<float4*>(spec + (size_t)j * FN);
+    uint4* __restrict__ out = reinterpret_cast<uint4*>(spec + (size_t)j * FN);
 #pragma unroll
-    for (int t = 0; t < sushi_fft::PER / 2; ++t)
-        out[sushi_fft::wslot_float4(tid, t)] = float4{v[2 * t].x, v[2 * t].y, v[2 * t + 1].x, v[2 * t + 1].y};
+    for (int u = 0; u < sushi_fft::PER / 4; ++u)
+        out[sushi_fft::wslot_uint4(tid, u)] = uint4{pack_h2(v[4 * u].x * sz, v[4 * u].y * sz), pack_h2(v[4 * u + 1].x * sz, v[4 * u + 1].y * sz),
+                                                    pack_h2(v[4 * u + 2].x * sz, v[4 * u + 2].y * sz), pack_h2(v[4 * u + 3].x * sz, v[4 * u + 3].y * sz)};
 }
 
 // last search of [0, n) whose first_seg is <= x
@@ -171,11 +191,13 @@ struct TemplConsts {
     float inv_m;         // 1 / M
     int flat;            // the pattern has no variance: cv2's result is all ones
     float c_sum_t;       // c * sum T: sum T I = y' + c_sum_t (block spectra are of the centred destination samples)
-    float inv_scale;     // 1 / the power-of-two scale of this search's pattern spectra (and so of its products)
+    float inv_scale;     // 1 / the power-of-two scale of this search's stored products Y
+    float mac_scale;     // what mac_kernel multiplies its float32 sums by when it stores them: scale of Y / (scale of Tt * scale of Z)
 };
 
 // ------------------------------------------------------------------------------------------
-// Pattern-segment spectra: Tt = conj(DFT(t_s zero padded)) / N.  The workgroup of a search's first
+// Pattern-segment spectra: Tt = conj(DFT(t_s zero padded)) / N, stored as the packed halves (Re Tt, -Im Tt) mac_kernel's
+// dot products take (mac_core.hpp) -- the scaled forward transform itself.  The workgroup of a search's first
 // segment also writes the search's scoring constants and the pair -> search map ifft_kernel reads.
 // ------------------------------------------------------------------------------------------
 struct TspecArgs {
@@ -184,7 +206,7 @@ struct TspecArgs {
     int n_sub;
     int sub_first_seg;
     int sub_first_pair;
-    cpx* tspec;                       // [segments of the sub-batch][FN]
+    uint32_t* tspec;                  // [segments of the sub-batch][FN] packed halves
     int* pairmap;                     // [pairs of the sub-batch] -> search index inside the sub-batch
     struct TemplConsts* tconst;       // [searches of the sub-batch]
     const double* src_s1;
@@ -205,7 +227,8 @@ void tspec_kernel(TspecArgs a) {
     const int s = seg - sd.first_seg;
     const int M = sd.tmpl_len;
     const TemplStats ts_all = templ_stats(a.src_s1, a.src_s2, sd.tmpl_off, M, a.centre);
-    const float scale = y_scale_for(ts_all.tnorm, (M + FFT_SEG - 1) / FFT_SEG, a.dst_stats[0]);
+    const float y_scale = y_scale_for(ts_all.tnorm, (M + FFT_SEG - 1) / FFT_SEG, a.dst_stats[0]);
+    const float t_scale = t_scale_for(ts_all.tnorm);
     if (s == 0) {
         const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, M);
         int* __restrict__ pm = a.pairmap + (sd.first_pair - a.sub_first_pair);
@@ -216,7 +239,8 @@ void tspec_kernel(TspecArgs a) {
             tc.tU = ts.tU; tc.inv_tnorm = (float)(1.0 / ts.tnorm); tc.tnorm = (float)ts.tnorm;
             tc.tmean = (float)ts.tmean; tc.flat = ts.flat ? 1 : 0;
             tc.inv_tnorm_c = ts.flat ? 0.f : (float)(1.0 / ts.tnorm_c); tc.inv_m = (float)(1.0 / (double)M);
-            tc.c_sum_t = (float)(a.dst_stats[1] * ts.tS1); tc.inv_scale = 1.0f / scale;
+            tc.c_sum_t = (float)(a.dst_stats[1] * ts.tS1); tc.inv_scale = 1.0f / y_scale;
+            tc.mac_scale = (float)((double)y_scale / ((double)t_scale * (double)z_scale_for(a.dst_stats[0])));
             a.tconst[k] = tc;
         }
     }
@@ -232,43 +256,48 @@ void tspec_kernel(TspecArgs a) {
     }
     sushi_fft::fft_split<FFT_LOGN, -1>(v, tid, lds, tw);
     to_load_order(v, tid, lds);
-    float4* __restrict__ out = reinterpret_cast<float4*>(a.tspec + (size_t)blockIdx.x * FN);
-    const float sc = scale / (float)FN;
+    uint4* __restrict__ out = reinterpret_cast<uint4*>(a.tspec + (size_t)blockIdx.x * FN);
+    const float sc = t_scale / (float)FN;
 #pragma unroll
-    for (int t = 0; t < sushi_fft::PER / 2; ++t)
-        out[sushi_fft::wslot_float4(tid, t)] = float4{v[2 * t].x * sc, -v[2 * t].y * sc, v[2 * t + 1].x * sc, -v[2 * t + 1].y * sc};
+    for (int u = 0; u < sushi_fft::PER / 4; ++u)
+        out[sushi_fft::wslot_uint4(tid, u)] = uint4{pack_h2(v[4 * u].x * sc, v[4 * u].y * sc), pack_h2(v[4 * u + 1].x * sc, v[4 * u + 1].y * sc),
+                                                    pack_h2(v[4 * u + 2].x * sc, v[4 * u + 2].y * sc), pack_h2(v[4 * u + 3].x * sc, v[4 * u + 3].y * sc)};
 }
 
 // ------------------------------------------------------------------------------------------
 // Frequency-domain multiply-accumulate.  A wave = MAC_SPW searches of one segment-count class, neighbours in the stream (window starts),
-// x MAC_BPW pairs of adjacent bins: lane = (search slot, bin pair).  All searches sit on the same absolute block grid,
-// so the lanes of a wave walk the union of their block ranges together (mac_core.hpp): the row Z_j(bins) is one
-// 128-byte line that the eight search slots read at the same address -- one L2 request serves eight searches -- and
-// every output Y_I(bins) of a search is a full 128-byte line written by eight neighbouring lanes.  Pattern spectra
-// live in registers (per lane: its own search's), a ring of SMAX / FFT_STEP outputs is live per lane.  No barriers.
+// x MAC_BPW entries of four adjacent bins: lane = (search slot, entry).  All searches sit on the same absolute block grid,
+// so the lanes of a wave walk the union of their block ranges together (mac_core.hpp): the row piece Z_j(32 bins) is one
+// 128-byte line that the eight search slots read at the same address -- one L2 request serves eight searches x 32 bins --
+// and every output Y_I(32 bins) of a search is a full 128-byte line written by eight neighbouring lanes.  Pattern spectra
+// live in registers (per lane: its own search's, one 32-bit word per bin), a ring of SMAX / FFT_STEP float32 outputs is
+// live per lane.  No barriers.
+// What bounds the kernel is the bytes a CU's L1 passes (~10 B per clock): with every operand a packed half a byte through
+// the L1 feeds twice the multiply-adds it fed as float32, and they are two to an instruction.
 // ------------------------------------------------------------------------------------------
 constexpr int MAC_SPW = 8;                       // searches per wave
-constexpr int MAC_BPW = 64 / MAC_SPW;            // bin pairs per wave
+constexpr int MAC_BPW = 64 / MAC_SPW;            // 4-bin entries per wave
 constexpr int MAC_WAVES = 4;
 constexpr int MAC_THREADS = MAC_WAVES * 64;
-constexpr int MAC_BW = MAC_BPW * MAC_WAVES;      // bin pairs per workgroup
+constexpr int MAC_BW = MAC_BPW * MAC_WAVES;      // entries per workgroup
 
 struct MacArgs {
-    const float4* spec;               // destination spectra, as pairs of bins
+    const uint4* spec;                // destination spectra, as 4-bin entries of packed halves
     int64_t spec_blocks;              // blocks of the stream; block `spec_blocks` is all zero
-    const float4* tspec;
-    uint2* y;                         // [pairs of the sub-batch][FN/2]: two bins = four halves per entry
+    const uint4* tspec;
+    uint4* y;                         // [pairs of the sub-batch][ROWE]
     const SearchDesc* searches;       // the sub-batch's searches
+    const TemplConsts* tconst;        // [searches of the sub-batch]: mac_scale
     const int* items;                 // [n_items][1 + MAC_SPW]: segment-count class, then search indices inside the sub-batch (-1 = none)
     int n_items;
     int sub_first_seg;
     int sub_first_pair;
     int chunk_group;                  // bin chunks an XCD works on at a time (a power of two dividing its share)
-    float4* dummy;                    // [MAC_DUMMY_LINES][MAC_THREADS] where the stores of lanes without a valid output go
+    uint4* dummy;                     // [MAC_DUMMY_LINES][MAC_THREADS] where the stores of lanes without a valid output go
 };
 
 constexpr int MAC_DUMMY_LINES = 1024;
-constexpr int MAC_CHUNKS = FN / 2 / MAC_BW;
+constexpr int MAC_CHUNKS = ROWE / MAC_BW;
 static_assert(MAC_CHUNKS % 8 == 0, "every XCD owns the same number of bin chunks");
 constexpr int MAC_ZR = 6;                        // rows per load instruction: divides every SMAX
 
@@ -285,28 +314,32 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 
 constexpr int MAC_SMAX_SHORT = mac_class_smax(MAC_SHORT_CLASSES - 1);   // 18: mac_kernel
 constexpr int MAC_SMAX_LONG = mac_class_smax(MAC_CLASSES - 1);           // 30: mac_long_kernel
-constexpr int MAC_CH = MAC_ZR;                   // rows one load instruction brings (lane = row x bin pair)
+constexpr int MAC_CH = MAC_ZR;                   // rows one load instruction brings (lane = row x entry)
 static_assert(MAC_CH <= MAC_SPW, "a load's rows are spread over the search slots");
 constexpr int MAC_AHEAD_ROWS = 36;               // rows in flight per wave (mac_kernel: a multiple of each of its SMAX; mac_long_kernel: one group): 4.5 KB
 
-// The walk of one wave (MAC_SPW searches x MAC_BPW bin pairs) for its segment-count class.  Rows reach the lanes in
-// two hops: a load instruction fetches MAC_CH consecutive rows at once (lane = (row, bin pair): 128 distinct bytes per
+__device__ __forceinline__ sushi_mac::h8 as_h8(const uint4 v) { return sushi_mac::h8{{v.x, v.y, v.z, v.w}}; }
+__device__ __forceinline__ uint4 as_uint4(const sushi_mac::h8 v) { return uint4{v.w[0], v.w[1], v.w[2], v.w[3]}; }
+
+// The walk of one wave (MAC_SPW searches x MAC_BPW entries) for its segment-count class.  Rows reach the lanes in
+// two hops: a load instruction fetches MAC_CH consecutive rows at once (lane = (row, entry): 128 distinct bytes per
 // row), LA = MAC_AHEAD_ROWS / SMAX groups ahead of their use into a register ring; one group ahead they are dropped
-// into the wave's private LDS buffer, from where every search slot reads the same row (a broadcast read).  The wave's
-// own LDS operations are ordered, so none of this needs a barrier.
+// into the wave's private LDS buffer -- the piece itself and its rotation by -i, which the imaginary parts' dot products
+// take (mac_core.hpp): made once here instead of once per search slot -- from where every search slot reads the same row
+// (a broadcast read).  The wave's own LDS operations are ordered, so none of this needs a barrier.
 // Every memory operation of the loop body is unconditional -- lanes without a row to fetch re-fetch a neighbour's,
 // lanes without a valid output store to a dummy line: the compiler then knows how many operations are in flight at every
 // point and waits for exactly the load it needs (a conditional one makes it drain everything, every group).
 template <int SMAX, bool ACCUM, int ZROWS>
 __device__ __forceinline__ void mac_chunk(const MacArgs& a, const int c0, const int wv_first, const int wv_last,
                                           const long long pair_lo, const long long pair_hi, const bool lane_chunk,
-                                          const sushi_mac::c2 (&tt)[SMAX], const float4* __restrict__ zsp, const int z_zero,
-                                          uint2* __restrict__ yout, uint2* __restrict__ dummy, const int slot,
-                                          const int fb, float4 (*zw)[ZROWS + 1][MAC_BPW]) {
-    using sushi_mac::c2;
+                                          const sushi_mac::h8 (&tt)[SMAX], const uint4* __restrict__ zsp, const int z_zero,
+                                          uint4* __restrict__ yout, uint4* __restrict__ dummy, const float sy, const int slot,
+                                          const int fb, uint4 (*zw)[ZROWS + 1][2][MAC_BPW]) {
+    using sushi_mac::acc4;
+    using sushi_mac::zrow;
     constexpr int STEP = FFT_STEP;
-    constexpr int HALF = FN / 2;                                // float4 (two-bin) elements per block
-    constexpr int AHEAD = SMAX <= MAC_SMAX_SHORT ? MAC_AHEAD_ROWS : SMAX;   // rows in flight
+    constexpr int AHEAD = SMAX < MAC_SMAX_SHORT ? MAC_AHEAD_ROWS : SMAX;    // rows in flight (the largest class of each kernel: what its registers allow)
     constexpr int NC = SMAX / MAC_CH;                           // load instructions per group
     constexpr int LA = AHEAD / SMAX;                            // groups between a load and its use
     constexpr int NQ = LA * NC;                                 // register ring, in loads
@@ -314,19 +347,24 @@ __device__ __forceinline__ void mac_chunk(const MacArgs& a, const int c0, const 
     static_assert(SMAX % MAC_CH == 0 && AHEAD % SMAX == 0 && SMAX <= ZROWS, "ring geometry");
     const int lrow = slot % MAC_CH;                              // the row of a load this lane fetches
     const bool loader = slot < MAC_CH;                           // ... and whether its copy is the one that goes to LDS
-    auto as_c2 = [](const float4 v) { return c2{v.x, v.y, v.z, v.w}; };
     // rows jrow + lrow of one load; blocks past the stream are the all-zero block
     auto load_rows = [&](const int jrow) {
         const int jj = jrow + lrow;
-        return zsp[(size_t)(jj < z_zero ? jj : z_zero) * HALF];
+        return zsp[(size_t)(jj < z_zero ? jj : z_zero) * ROWE];
     };
-    c2 acc[SMAX / STEP];
+    // a loaded piece into an LDS buffer: the row as it is and rotated
+    auto drop = [&](const int buf, const int c, const uint4 piece) {
+        const int row = loader ? MAC_CH * c + slot : ZROWS;
+        zw[buf][row][0][fb] = piece;
+        zw[buf][row][1][fb] = as_uint4(sushi_mac::rot_mi(as_h8(piece)));
+    };
+    acc4 acc[SMAX / STEP];
 #pragma unroll
-    for (int r = 0; r < SMAX / STEP; ++r) acc[r] = sushi_mac::zero2();
-    float4 rq[NQ];
+    for (int r = 0; r < SMAX / STEP; ++r) acc[r] = sushi_mac::zero_acc();
+    uint4 rq[NQ];
     // prologue: group 0 straight into LDS buffer 0, groups 1 .. LA into the register ring
     {
-        float4 first[NC];
+        uint4 first[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) first[c] = load_rows(wv_first + c0 + MAC_CH * c);
 #pragma unroll
@@ -335,7 +373,7 @@ __device__ __forceinline__ void mac_chunk(const MacArgs& a, const int c0, const 
             for (int c = 0; c < NC; ++c) rq[(g % LA) * NC + c] = load_rows(wv_first + c0 + SMAX * g + MAC_CH * c);
         }
 #pragma unroll
-        for (int c = 0; c < NC; ++c) zw[0][loader ? MAC_CH * c + slot : ZROWS][fb] = first[c];
+        for (int c = 0; c < NC; ++c) drop(0, c, first[c]);
     }
     for (int jb = wv_first; jb <= wv_last; jb += SMAX * UNROLL) {
 #pragma unroll
@@ -344,27 +382,35 @@ __device__ __forceinline__ void mac_chunk(const MacArgs& a, const int c0, const 
             // the next group leaves the register ring for the other LDS buffer (this wave read that buffer one group
             // ago: its LDS operations are in order) ...
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-                zw[(t + 1) & 1][loader ? MAC_CH * c + slot : ZROWS][fb] = rq[((t + 1) % LA) * NC + c];
+            for (int c = 0; c < NC; ++c) drop((t + 1) & 1, c, rq[((t + 1) % LA) * NC + c]);
             // ... and its ring slots take the loads of the group LA further on
 #pragma unroll
             for (int c = 0; c < NC; ++c) rq[((t + 1) % LA) * NC + c] = load_rows(jg + c0 + SMAX * (1 + LA) + MAC_CH * c);
-            auto get_z = [&](const int u) { return as_c2(zw[t & 1][u][fb]); };
-            auto store = [&](const int i, const bool valid, const c2 v) {
-                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            auto get_z = [&](const int u) { return zrow{as_h8(zw[t & 1][u][0][fb]), as_h8(zw[t & 1][u][1][fb])}; };
+            auto store = [&](const int i, const bool valid, const acc4& v) {
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
                 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                 // (a lane-predicated store instead of the dummy line was tried: the compiler branches around it and
                 // falls back to draining the load queue, tools/experiments/README.md)
                 const bool ok = valid && lane_chunk && jg <= wv_last;
-                u2* __restrict__ dst = reinterpret_cast<u2*>(ok ? yout + (size_t)i * HALF : dummy);
-                float ax = v.ax, ay = v.ay, bx = v.bx, by = v.by;
+                u4* __restrict__ dst = reinterpret_cast<u4*>(ok ? yout + (size_t)i * ROWE : dummy);
+                float re[sushi_mac::BINS], im[sushi_mac::BINS];
+#pragma unroll
+                for (int k = 0; k < sushi_mac::BINS; ++k) { re[k] = v.re[k] * sy; im[k] = v.im[k] * sy; }   // to the scale of Y
                 if (ACCUM) {                                    // patterns beyond one pass: the row accumulates (in halves)
-                    const u2 prev = *dst;
-                    const h2 p0 = __builtin_bit_cast(h2, prev.x), p1 = __builtin_bit_cast(h2, prev.y);
-                    ax += (float)p0.x; ay += (float)p0.y; bx += (float)p1.x; by += (float)p1.y;
+                    const u4 prev = *dst;
+#pragma unroll
+                    for (int k = 0; k < sushi_mac::BINS; ++k) {
+                        const h2 p = __builtin_bit_cast(h2, prev[k]);
+                        re[k] += (float)p.x; im[k] += (float)p.y;
+                    }
                 }
-                const h2 q0 = {(_Float16)ax, (_Float16)ay}, q1 = {(_Float16)bx, (_Float16)by};   // v_cvt_pk_f16_f32: round to nearest even
-                const u2 o = {__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)};
+                u4 o;
+#pragma unroll
+                for (int k = 0; k < sushi_mac::BINS; ++k) {
+                    const h2 q = {(_Float16)re[k], (_Float16)im[k]};                 // v_cvt_pk_f16_f32: round to nearest even
+                    o[k] = __builtin_bit_cast(unsigned, q);
+                }
                 // Y is streamed once and read back once by another kernel: non-temporal stores keep the block spectra in
                 // L2.  A store with dummy lanes in it goes the write-back way instead (one store instruction on either
                 // path): the dummy lines are overwritten in L2 again and again and never reach HBM, whereas non-temporal
@@ -372,26 +418,29 @@ __device__ __forceinline__ void mac_chunk(const MacArgs& a, const int c0, const 
                 if (__ballot(ok) == ~0ull) __builtin_nontemporal_store(o, dst);
                 else *dst = o;
             };
-            sushi_mac::mac_group<SMAX, STEP>((long long)jg, pair_lo, pair_hi, tt, acc, get_z, store);
+            // (a row of the large classes meets three or more segments: one row of look-ahead covers the LDS latency, and
+            // their registers do not hold two)
+            sushi_mac::mac_group<SMAX, STEP, (SMAX >= MAC_SMAX_SHORT ? 2 : 3)>((long long)jg, pair_lo, pair_hi, tt, acc, get_z, store);
         }
     }
 }
 
 template <int SMAX, int ZROWS>
-__device__ __forceinline__ void mac_item(const MacArgs& a, const int* __restrict__ item, const int f2, const int slot,
-                                         float4 (*zw)[ZROWS + 1][MAC_BPW]) {
-    using sushi_mac::c2;
+__device__ __forceinline__ void mac_item(const MacArgs& a, const int* __restrict__ item, const int e0, const int slot,
+                                         uint4 (*zw)[ZROWS + 1][2][MAC_BPW]) {
+    using sushi_mac::h8;
     constexpr int STEP = FFT_STEP;
-    constexpr int HALF = FN / 2;
     const int fb = threadIdx.x % MAC_BPW;
     const int k = item[1 + slot];                               // this lane's search
     long long pair_lo = 0, pair_hi = 0;
     int jb0 = 0x7fffffff, jb1 = -0x7fffffff, n_seg = 0, first_seg = 0, first_pair = 0;
+    float sy = 0.f;
     if (k >= 0) {
         const SearchDesc sd = a.searches[k];
         const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
         pair_lo = lay.pair0; pair_hi = lay.pair0 + lay.n_pairs; n_seg = lay.n_seg;
         first_seg = sd.first_seg - a.sub_first_seg; first_pair = sd.first_pair - a.sub_first_pair;
+        sy = a.tconst[k].mac_scale;
         long long g0, g1;
         sushi_mac::group_range<SMAX, STEP>(pair_lo, pair_hi, &g0, &g1);
         jb0 = (int)g0; jb1 = (int)g1;                            // block indices fit 31 bits (sushi_hip_stream_add_spectra)
@@ -400,21 +449,20 @@ __device__ __forceinline__ void mac_item(const MacArgs& a, const int* __restrict
     const int wv_first = __builtin_amdgcn_readfirstlane(wave_min_i32(jb0));
     const int wv_last = __builtin_amdgcn_readfirstlane(wave_max_i32(jb1));
     const int wv_seg = __builtin_amdgcn_readfirstlane(wave_max_i32(n_seg));
-    const float4* __restrict__ tsp = a.tspec + (size_t)first_seg * HALF + f2;
-    uint2* __restrict__ yout = a.y + (size_t)first_pair * HALF + f2;
-    const float4* __restrict__ zsp = a.spec + f2;
+    const uint4* __restrict__ tsp = a.tspec + (size_t)first_seg * ROWE + e0;
+    uint4* __restrict__ yout = a.y + (size_t)first_pair * ROWE + e0;
+    const uint4* __restrict__ zsp = a.spec + e0;
     // one 16-byte slot per wave: the invalid lanes of a store instruction then add one request to it instead of a line per
     // search slot (a fifth of mac_kernel's write requests were dummy lines, and the CU's L1 write path is what it waits for)
-    uint2* __restrict__ dummy = reinterpret_cast<uint2*>(a.dummy + (size_t)(blockIdx.x % MAC_DUMMY_LINES) * MAC_THREADS + (threadIdx.x & ~63));
+    uint4* __restrict__ dummy = a.dummy + (size_t)(blockIdx.x % MAC_DUMMY_LINES) * MAC_THREADS + (threadIdx.x & ~63);
     const int z_zero = (int)(a.spec_blocks < 0x7fffffff ? a.spec_blocks : 0x7fffffff);
-    auto as_c2 = [](const float4 v) { return c2{v.x, v.y, v.z, v.w}; };
     for (int c0 = 0; c0 < wv_seg; c0 += SMAX) {                 // patterns longer than SMAX segments: SMAX at a time
-        c2 tt[SMAX];
+        h8 tt[SMAX];
 #pragma unroll
-        for (int s = 0; s < SMAX; ++s) tt[s] = (c0 + s) < n_seg ? as_c2(tsp[(size_t)(c0 + s) * HALF]) : sushi_mac::zero2();
+        for (int s = 0; s < SMAX; ++s) tt[s] = (c0 + s) < n_seg ? as_h8(tsp[(size_t)(c0 + s) * ROWE]) : sushi_mac::zero_h8();
         const bool lane_chunk = c0 < n_seg;
-        if (c0 == 0) mac_chunk<SMAX, false, ZROWS>(a, c0, wv_first, wv_last, pair_lo, pair_hi, lane_chunk, tt, zsp, z_zero, yout, dummy, slot, fb, zw);
-        else if (SMAX == MAC_SMAX_LONG) mac_chunk<SMAX, true, ZROWS>(a, c0, wv_first, wv_last, pair_lo, pair_hi, lane_chunk, tt, zsp, z_zero, yout, dummy, slot, fb, zw);
+        if (c0 == 0) mac_chunk<SMAX, false, ZROWS>(a, c0, wv_first, wv_last, pair_lo, pair_hi, lane_chunk, tt, zsp, z_zero, yout, dummy, sy, slot, fb, zw);
+        else if (SMAX == MAC_SMAX_LONG) mac_chunk<SMAX, true, ZROWS>(a, c0, wv_first, wv_last, pair_lo, pair_hi, lane_chunk, tt, zsp, z_zero, yout, dummy, sy, slot, fb, zw);
     }
 }
 
@@ -422,8 +470,7 @@ __device__ __forceinline__ void mac_item(const MacArgs& a, const int* __restrict
 // owns MAC_CHUNKS / 8 bin chunks, takes them `chunk_group` at a time and walks the items in stream order for each
 // group, so that the workgroups in flight on an XCD are the same few chunks of neighbouring items, whose windows
 // overlap: a row fetched for one is found in that XCD's L2 by the others.
-template <int ZROWS>
-__device__ __forceinline__ void mac_place(const MacArgs& a, int* item_idx, int* f2, int* slot, int* wave) {
+__device__ __forceinline__ void mac_place(const MacArgs& a, int* item_idx, int* e0, int* slot, int* wave) {
     constexpr int CPX = MAC_CHUNKS / 8;                         // chunks per XCD
     const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
     const int cg = a.chunk_group;
@@ -434,20 +481,20 @@ __device__ __forceinline__ void mac_place(const MacArgs& a, int* item_idx, int* 
     const int chunk = xcd * CPX + grp * cg + (in_grp - *item_idx * cg);
     const int lane = threadIdx.x & 63;
     *wave = threadIdx.x >> 6;
-    *f2 = chunk * MAC_BW + *wave * MAC_BPW + (lane % MAC_BPW);   // which pair of bins
+    *e0 = chunk * MAC_BW + *wave * MAC_BPW + (lane % MAC_BPW);   // which entry of four bins
     *slot = lane / MAC_BPW;                                      // which of the item's searches
 }
 
 __global__ __launch_bounds__(MAC_THREADS, 3)
 void mac_kernel(MacArgs a) {
-    __shared__ float4 zring[MAC_WAVES][2][MAC_SMAX_SHORT + 1][MAC_BPW];   // per wave: two groups of rows (+ a row nobody reads)
-    int item_idx, f2, slot, wave;
-    mac_place<MAC_SMAX_SHORT>(a, &item_idx, &f2, &slot, &wave);
+    __shared__ uint4 zring[MAC_WAVES][2][MAC_SMAX_SHORT + 1][2][MAC_BPW];   // per wave: two groups of rows, each with its rotation (+ a row nobody reads)
+    int item_idx, e0, slot, wave;
+    mac_place(a, &item_idx, &e0, &slot, &wave);
     const int* __restrict__ item = a.items + (size_t)item_idx * (1 + MAC_SPW);
     switch (item[0]) {                                          // class c holds patterns of up to 6 (c + 1) segments
-        case 0: mac_item<6, MAC_SMAX_SHORT>(a, item, f2, slot, zring[wave]); break;
-        case 1: mac_item<12, MAC_SMAX_SHORT>(a, item, f2, slot, zring[wave]); break;
-        default: mac_item<18, MAC_SMAX_SHORT>(a, item, f2, slot, zring[wave]); break;
+        case 0: mac_item<6, MAC_SMAX_SHORT>(a, item, e0, slot, zring[wave]); break;
+        case 1: mac_item<12, MAC_SMAX_SHORT>(a, item, e0, slot, zring[wave]); break;
+        default: mac_item<18, MAC_SMAX_SHORT>(a, item, e0, slot, zring[wave]); break;
     }
 }
 
@@ -455,13 +502,13 @@ void mac_kernel(MacArgs a) {
 // One pass instead of mac_kernel's two with Y read back in between (BASELINE configs[4]: half of the events).
 __global__ __launch_bounds__(MAC_THREADS, 2)
 void mac_long_kernel(MacArgs a) {
-    __shared__ float4 zring[MAC_WAVES][2][MAC_SMAX_LONG + 1][MAC_BPW];
-    int item_idx, f2, slot, wave;
-    mac_place<MAC_SMAX_LONG>(a, &item_idx, &f2, &slot, &wave);
+    __shared__ uint4 zring[MAC_WAVES][2][MAC_SMAX_LONG + 1][2][MAC_BPW];
+    int item_idx, e0, slot, wave;
+    mac_place(a, &item_idx, &e0, &slot, &wave);
     const int* __restrict__ item = a.items + (size_t)item_idx * (1 + MAC_SPW);
     switch (item[0]) {
-        case 3: mac_item<24, MAC_SMAX_LONG>(a, item, f2, slot, zring[wave]); break;
-        default: mac_item<30, MAC_SMAX_LONG>(a, item, f2, slot, zring[wave]); break;
+        case 3: mac_item<24, MAC_SMAX_LONG>(a, item, e0, slot, zring[wave]); break;
+        default: mac_item<30, MAC_SMAX_LONG>(a, item, e0, slot, zring[wave]); break;
     }
 }
 
@@ -818,7 +865,7 @@ __device__ __forceinline__ float pair_error_model(float zn, float zn_c, float ma
     const float eps = 5.9604645e-8f;                             // 2^-24
     // quantisation of the Y row: every stored half is off by <= 2^-11 of its size (round to nearest), independently; the
     // inverse transform sums N of them: variance (2^-22 / 3) * sum |Y(f)|^2 (+ the subnormal floor), Y_KQ deviations
-    const float sigma_y = sqrtf(q2 * (1.0f / 3.0f) * 2.3841858e-7f + (float)FN * 1.2e-15f) * inv_scale;   // 2^-22 / 3: (2^-11)^2, uniform
+    const float sigma_y = sqrtf(q2 * 2.3841858e-7f + (float)FN * 1.2e-15f) * inv_scale;   // 3 x 2^-22 / 3: the row's own rounding + its two factors' (module header)
     if (METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED) {
         const float ism = sqrtf(tc.inv_m);
         const float z = fmaxf(zn, zn_c);
@@ -1095,7 +1142,7 @@ struct WsLayout { size_t tspec, y, cand, pair_lb, pairmap, tconst, tiles, candbu
 inline WsLayout ws_layout(int64_t pairs, int64_t segs, int64_t searches) {
     WsLayout w;
     size_t o = 0;
-    w.tspec = o; o += align_up((size_t)segs * FN * sizeof(cpx), 256);
+    w.tspec = o; o += align_up((size_t)segs * ROW_BYTES, 256);                   // packed halves: 4 bytes per bin
     w.y = o; o += align_up((size_t)pairs * FN * 2 * sizeof(uint16_t), 256);      // packed halves: 4 bytes per bin
     w.cand = o; o += align_up((size_t)pairs * FFT_ROW * sizeof(unsigned long long), 256);
     w.pair_lb = o; o += align_up((size_t)pairs * sizeof(float), 256);
@@ -1103,7 +1150,7 @@ inline WsLayout ws_layout(int64_t pairs, int64_t segs, int64_t searches) {
     w.tconst = o; o += align_up((size_t)searches * sizeof(TemplConsts), 256);
     w.tiles = o; o += align_up((size_t)pairs * TILES_PER_PAIR * sizeof(TileDesc), 256);
     w.candbuf = o; o += align_up((size_t)cand_capacity(pairs) * sizeof(int32_t), 256);
-    w.dummy = o; o += align_up((size_t)MAC_DUMMY_LINES * MAC_THREADS * sizeof(float4), 256);
+    w.dummy = o; o += align_up((size_t)MAC_DUMMY_LINES * MAC_THREADS * sizeof(uint4), 256);
     w.total = o;
     return w;
 }
@@ -1352,7 +1399,7 @@ int sushi_hip_fft_block(void) { return FFT_SEG; }
 int sushi_hip_fft_slot_of_bin(int bin) { return (bin < 0 || bin >= FN) ? -1 : sushi_fft::wslot_of_bin(bin); }
 
 size_t sushi_hip_stream_spectra_bytes(int64_t n) {
-    return n <= 0 ? 0 : (size_t)((n + FFT_SEG - 1) / FFT_SEG + 1) * FN * sizeof(cpx);
+    return n <= 0 ? 0 : (size_t)((n + FFT_SEG - 1) / FFT_SEG + 1) * ROW_BYTES;
 }
 
 int sushi_hip_fft_layout(int64_t win_start, int32_t n_pos, int32_t tmpl_len, int32_t* n_pairs, int32_t* n_seg) {
@@ -1372,10 +1419,10 @@ int sushi_hip_stream_add_spectra(SushiHipStream* s, void* mem_dev, size_t mem_by
     // one block more than the stream has: its samples are all past the end, so its spectrum is zero
     if (s->dtype == SUSHI_HIP_F32)
         hipLaunchKernelGGL(spectra_kernel<float>, dim3((unsigned)s->blocks + 1), dim3(FT), 0, (hipStream_t)hip_stream,
-                           (const float*)s->raw, s->n, (cpx*)mem_dev, (const double*)s->stats);
+                           (const float*)s->raw, s->n, (uint32_t*)mem_dev, (const double*)s->stats);
     else
         hipLaunchKernelGGL(spectra_kernel<uint8_t>, dim3((unsigned)s->blocks + 1), dim3(FT), 0, (hipStream_t)hip_stream,
-                           (const uint8_t*)s->raw, s->n, (cpx*)mem_dev, (const double*)s->stats);
+                           (const uint8_t*)s->raw, s->n, (uint32_t*)mem_dev, (const double*)s->stats);
     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
     s->spec = mem_dev;
     s->spec_bytes = need;
@@ -1516,8 +1563,8 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         const int n_sub = sbt.b0 - sbt.a0;
         const WsLayout wl = ws_layout(sbt.pairs, sbt.segs, n_sub);
         char* wsp = b->mem + b->lay.ws;
-        cpx* tspec = (cpx*)(wsp + wl.tspec);
-        cpx* y = (cpx*)(wsp + wl.y);
+        uint32_t* tspec = (uint32_t*)(wsp + wl.tspec);
+        uint4* y = (uint4*)(wsp + wl.y);
         unsigned long long* cand = (unsigned long long*)(wsp + wl.cand);
         int* pairmap = (int*)(wsp + wl.pairmap);
         float* pair_lb = (float*)(wsp + wl.pair_lb);
@@ -1538,10 +1585,10 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         t0 = prof_begin(pc, st);
         {
             MacArgs ma;
-            ma.spec = (const float4*)dst->spec; ma.spec_blocks = dst->blocks; ma.tspec = (const float4*)tspec;
-            ma.y = (uint2*)y; ma.searches = searches_dev + sbt.a0; ma.sub_first_seg = sbt.first_seg;
+            ma.spec = (const uint4*)dst->spec; ma.spec_blocks = dst->blocks; ma.tspec = (const uint4*)tspec;
+            ma.y = y; ma.searches = searches_dev + sbt.a0; ma.tconst = tconst; ma.sub_first_seg = sbt.first_seg;
             ma.sub_first_pair = sbt.first_pair;
-            ma.dummy = (float4*)(wsp + wl.dummy);
+            ma.dummy = (uint4*)(wsp + wl.dummy);
             for (int kern = 0; kern < 2; ++kern) {
                 if (sbt.item_count[kern] == 0) continue;
                 ma.items = items + (size_t)sbt.item_first[kern] * (1 + MAC_SPW);

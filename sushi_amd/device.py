@@ -125,7 +125,7 @@ class DeviceStream(object):
 
     def spectra(self):
         self.searchable()
-        return self._view(_native.VIEW_SPECTRA, torch.float32)
+        return self._view(_native.VIEW_SPECTRA, torch.float16)      # (re, im) pairs, one power-of-two scale per stream
 
     def nbytes(self):
         return self.raw.numel() * self.raw.element_size() + self._mem.numel() + \

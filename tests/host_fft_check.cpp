@@ -89,15 +89,13 @@ static double run_wave(const std::vector<cpx>& tw, unsigned seed) {
     std::vector<cd> r(N);
     for (int n = 0; n < N; ++n) r[n] = cd(x[n].x, x[n].y);
     ref_fft(r, DIR);
-    // what a kernel does: a stored spectrum in slot order, loaded as float4 = two registers
+    // what a kernel does: a stored spectrum in slot order, loaded as 4-bin entries = four registers
     std::vector<cpx> stored(N);
     for (int f = 0; f < N; ++f) stored[wslot_of_bin(f)] = x[f];
     std::vector<cpx> regs((size_t)NTS * PER);
     for (int tid = 0; tid < NTS; ++tid)
-        for (int t = 0; t < 8; ++t) {
-            regs[(size_t)tid * PER + 2 * t] = stored[2 * wslot_float4(tid, t)];
-            regs[(size_t)tid * PER + 2 * t + 1] = stored[2 * wslot_float4(tid, t) + 1];
-        }
+        for (int u = 0; u < 4; ++u)
+            for (int k = 0; k < 4; ++k) regs[(size_t)tid * PER + 4 * u + k] = stored[4 * wslot_uint4(tid, u) + k];
     for (int tid = 0; tid < NTS; ++tid)
         for (int q = 0; q < PER; ++q) {
             const cpx a = regs[(size_t)tid * PER + q], b = x[wbin(tid, q)];

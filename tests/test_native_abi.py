@@ -34,7 +34,7 @@ def test_host_only_entry_points():
     assert L.sushi_hip_stream_bytes(0, 1, 0) == 0 and L.sushi_hip_stream_bytes(10, 7, 0) == 0
     plain, searchable = L.sushi_hip_stream_bytes(100000, _native.F32, 0), L.sushi_hip_stream_bytes(100000, _native.F32, 1)
     assert plain >= 100000 * 4 + 2 * 100001 * 8 + 100001 * 4 and plain % 256 == 0
-    assert L.sushi_hip_stream_spectra_bytes(4097) == 3 * N * 8 and L.sushi_hip_stream_spectra_bytes(0) == 0
+    assert L.sushi_hip_stream_spectra_bytes(4097) == 3 * N * 4 and L.sushi_hip_stream_spectra_bytes(0) == 0
     assert searchable - plain == (L.sushi_hip_stream_spectra_bytes(100000) + 255) // 256 * 256
     # argument validation happens before any HIP call
     h = C.c_void_p()
