@@ -15,6 +15,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 summary, out, workload, commit = sys.argv[1:5]
+# optional: a TCP summary (tools/summarize_pmc.py over a TCP_TCC_WRITE_REQ_sum pass) and "kernel=bytes" pairs, for kernels whose
+# WRITE_SIZE pass is missing: write bytes from the L1s' 64-byte write requests, or from the kernel's own store count where that
+# is exact -- recorded as such per kernel ("write_source")
+tcp_summary = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] != "-" else None
+computed = dict(a.split("=") for a in sys.argv[6:])
 rows = {}                                                  # template instances of one kernel (mac_kernel<0..5>: one dispatch
 for r in csv.DictReader(open(summary)):                    # each per step) add up to that kernel's bytes per step
     k = r['kernel'].split('<')[0]
@@ -25,13 +30,26 @@ for r in csv.DictReader(open(summary)):                    # each per step) add 
         rows[k]['dispatches'] = str(max(int(rows[k]['dispatches']), int(r['dispatches'])))
     else:
         rows[k] = dict(r)
+tcp = {}
+if tcp_summary:
+    for r in csv.DictReader(open(tcp_summary)):
+        if r.get('TCP_TCC_WRITE_REQ_sum'):
+            tcp[r['kernel'].split('<')[0]] = float(r['TCP_TCC_WRITE_REQ_sum']) * 64.0
 res = {}
 for k, fetch_scale in (('ifft_kernel', 2.0), ('mac_kernel', 2.0), ('tspec_kernel', 1.0), ('refine_kernel', 1.0),
                        ('collect_kernel', 2.0), ('exact_tiles_kernel', 1.0)):
-    if k in rows and rows[k].get('FETCH_SIZE') and rows[k].get('WRITE_SIZE'):
-        res[k] = {"fetch_bytes": float(rows[k]['FETCH_SIZE']) * 1024 * fetch_scale,
-                  "write_bytes": float(rows[k]['WRITE_SIZE']) * 1024,
-                  "fetch_scale_applied": fetch_scale, "dispatches_averaged": int(rows[k]['dispatches'])}
+    if k not in rows or not rows[k].get('FETCH_SIZE'):
+        continue
+    if rows[k].get('WRITE_SIZE'):
+        wb, ws = float(rows[k]['WRITE_SIZE']) * 1024, "WRITE_SIZE"
+    elif k in tcp:
+        wb, ws = tcp[k], "TCP_TCC_WRITE_REQ_sum x 64 B (no WRITE_SIZE pass)"
+    elif k in computed:
+        wb, ws = float(computed[k]), "the kernel's own stores, counted (no WRITE_SIZE pass)"
+    else:
+        continue
+    res[k] = {"fetch_bytes": float(rows[k]['FETCH_SIZE']) * 1024 * fetch_scale, "write_bytes": wb, "write_source": ws,
+              "fetch_scale_applied": fetch_scale, "dispatches_averaged": int(rows[k]['dispatches'])}
 try:
     allw = json.load(open(out))
 except Exception:
