@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SUSHI_HIP_ABI_VERSION 7
+#define SUSHI_HIP_ABI_VERSION 8   /* 8: block spectra are packed halves (sushi_hip_stream_spectra_bytes, SUSHI_HIP_VIEW_SPECTRA) */
 
 #if defined(__GNUC__)
 #define SUSHI_HIP_API __attribute__((visibility("default")))
