@@ -574,6 +574,10 @@ def main():
                     traffic = traffic_bytes / (dom_ms * 1e-3) / 1e9
                     step_traffic = float(sum(k["fetch_bytes"] + k["write_bytes"] for k in entry["kernels"].values()))
                     traffic_note = "%s @ %s" % (entry.get("source"), entry.get("source_commit"))
+                    # where a kernel's write bytes are not a WRITE_SIZE pass (tools/make_pmc_traffic.py), say what they are
+                    others = sorted(set(k.get("write_source", "WRITE_SIZE") for k in entry["kernels"].values()) - {"WRITE_SIZE"})
+                    if others:
+                        traffic_note += "; reads: FETCH_SIZE; writes: " + " / ".join(others)
             except Exception:
                 pass
             roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
