@@ -191,6 +191,95 @@ def match_template_fft(search, templ, corr_f32: bool = True, method: str = SQDIF
     return out.reshape(1, -1)
 
 
+def optimal_dft_size(n: int) -> int:
+    """cv::getOptimalDFTSize: the smallest 2^a 3^b 5^c >= n (OpenCV holds them as a table; the same numbers)."""
+    if n <= 1:
+        return 1
+    best = None
+    p5 = 1
+    while p5 < 2 * n:
+        p35 = p5
+        while p35 < 2 * n:
+            v = p35
+            while v < n:
+                v *= 2
+            best = v if best is None or v < best else best
+            p35 *= 3
+        p5 *= 5
+    return int(best)
+
+
+def cross_correlate_cv2_model(search_row: np.ndarray, templ_row: np.ndarray) -> np.ndarray:
+    """A NOISE MODEL of cv2's crossCorr (OpenCV imgproc/templmatch.cpp, the function behind wav.py:185), not a restatement
+    of its bits: the same blocking and the same ARITHMETIC PRECISION, through SciPy's FFT instead of OpenCV's.
+
+      * block of result columns  = cvRound(4.5 * M), at least 256 - M + 1, at most P;
+        DFT length               = getOptimalDFTSize(block + M - 1) (>= 2); block recomputed as length - M + 1
+      * working depth (`maxDepth`): CV_64F when the image is deeper than CV_8S (float32 streams), otherwise CV_32F --
+        **uint8 streams (the reference's default sample_type, sushi.py:769) go through a float32 DFT**
+      * per block: image tile (block + M - 1 samples, zero padded) -> real DFT -> mulSpectrums(.., conjB=true) with the
+        template's spectrum -> inverse DFT with DFT_SCALE -> the first `block` values, converted to the CV_32F result
+
+    Returns corr as float32 (what matchTemplate's result matrix holds before common_matchTemplate runs).  Real cv2
+    differs from this model in WHICH rounding errors it commits (another FFT factorisation, SIMD reductions), not in
+    their size: use it to see how far the real call can sit from the exactly rounded oracle, never as a parity target."""
+    import scipy.fft
+    s, t = np.asarray(search_row), np.asarray(templ_row)
+    L, M = s.shape[0], t.shape[0]
+    P = L - M + 1
+    work = np.float64 if s.dtype == np.float32 else np.float32          # maxDepth
+    cwork = np.complex128 if work == np.float64 else np.complex64
+    block = int(round(M * 4.5))                                         # cvRound: half to even, as Python's round
+    block = max(block, 256 - M + 1)
+    block = min(block, P)
+    n_dft = max(optimal_dft_size(block + M - 1), 2)
+    block = min(n_dft - M + 1, P)
+    tpad = np.zeros(n_dft, work)
+    tpad[:M] = t
+    tspec = scipy.fft.rfft(tpad).astype(cwork, copy=False)
+    out = np.empty(P, np.float32)
+    for x in range(0, P, block):
+        bsz = min(block, P - x)
+        tile = np.zeros(n_dft, work)
+        n_in = min(bsz + M - 1, L - x)
+        tile[:n_in] = s[x:x + n_in]
+        spec = scipy.fft.rfft(tile).astype(cwork, copy=False)
+        spec *= np.conj(tspec)                                          # mulSpectrums(a, b, c, 0, conjB = true)
+        out[x:x + bsz] = scipy.fft.irfft(spec, n_dft)[:bsz].astype(np.float32)
+    return out
+
+
+def match_template_cv2_model(search, templ, method: str = SQDIFF_NORMED) -> np.ndarray:
+    """cv2.matchTemplate as `cross_correlate_cv2_model` + the exact epilogue: what the REAL call may return, to within
+    the identity of its rounding errors.  tests/test_cv2_noise_model.py measures its distance to the exactly rounded
+    oracle (DESIGN.md section 4 quotes the numbers)."""
+    s = _as_row(search)
+    t = _as_row(templ, s.dtype)
+    L, M = s.shape[0], t.shape[0]
+    if M <= 0 or L < M:
+        raise ValueError("template larger than search image (cv2.error in the reference)")
+    P = L - M + 1
+    corr = np.ascontiguousarray(cross_correlate_cv2_model(s, t).astype(np.float64))
+    s64 = s.astype(np.float64)
+    sq = np.zeros(L + 1, np.float64)
+    np.cumsum(s64 * s64, out=sq[1:])
+    t64 = t.astype(np.float64)
+    out = np.empty(P, np.float32)
+    if method == CCOEFF_NORMED:
+        s1 = np.zeros(L + 1, np.float64)
+        np.cumsum(s64, out=s1[1:])
+        rc = _load().oracle_finish_ccoeff_normed(corr.ctypes.data, s1.ctypes.data, sq.ctypes.data, P, M,
+                                                 float(t64.sum()), float((t64 * t64).sum()), out.ctypes.data, 1)
+    elif method == SQDIFF_NORMED:
+        rc = _load().oracle_finish_sqdiff_normed(corr.ctypes.data, sq.ctypes.data, P, M,
+                                                 float(t64.sum()), float((t64 * t64).sum()), out.ctypes.data, 1)
+    else:
+        raise ValueError("unknown method %r" % (method,))
+    if rc != 0:
+        raise RuntimeError("oracle error %d" % rc)
+    return out.reshape(1, -1)
+
+
 def match_template(search, templ, corr_f32: bool = True, method: str = SQDIFF_NORMED) -> np.ndarray:
     """Dispatch on size: direct C below ~2e9 MACs, FFT above."""
     s = _as_row(search)

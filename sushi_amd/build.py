@@ -27,7 +27,7 @@ UNITS = [
     # -fno-slp-vectorize: the SLP pass packs the complex MACs into v_pk_fma_f32 and pays for it in
     # register shuffles (v_mov / accvgpr traffic); plain v_fma_f32 already issues at the f32 peak rate.
     ("sushi_fft", ["-fno-slp-vectorize"],
-     [os.path.join(CSRC, "fft_core.hpp"), os.path.join(CSRC, "mac_core.hpp"), TWIDDLE_INC]),
+     [os.path.join(CSRC, "fft_core.hpp"), os.path.join(CSRC, "mac_core.hpp"), TWIDDLE_INC, os.path.join(CSRC, "_gen_dft16_f16.inc")]),
 ]
 
 
@@ -53,6 +53,36 @@ def write_twiddles(n=16384):
     return TWIDDLE_INC
 
 
+DFT16_INC = os.path.join(CSRC, "_gen_dft16_f16.inc")
+
+
+def write_dft16_operands():
+    """The B operands of ifft_kernel's first pass on the matrix pipe (fft_core.hpp dft16_operand): for each of the four products
+    (real parts of the result: high / low half of the matrix; imaginary parts: high / low) and each lane, eight halves as four
+    32-bit words.  Inverse transform (DIR = +1)."""
+    import numpy as np
+    words = []
+    for form in (0, 1):
+        vals = np.empty((64, 8), np.float64)
+        for l in range(64):
+            for j in range(8):
+                k, n = 8 * (l >> 4) + j, l & 15
+                kk, part = k & 15, k >> 4
+                ang = 2.0 * math.pi * ((n * kk) & 15) / 16.0
+                wr, wi = math.cos(ang), math.sin(ang)
+                vals[l, j] = (wr if part == 0 else -wi) if form == 0 else (wi if part == 0 else wr)
+        hi = vals.astype(np.float16)
+        lo = (vals - hi.astype(np.float64)).astype(np.float16)
+        for part in (hi, lo):
+            words.append(np.ascontiguousarray(part).view(np.uint32).reshape(-1))
+    flat = np.concatenate(words)
+    text = "".join("0x%08xu,%s" % (int(v), "\n" if i % 8 == 7 else " ") for i, v in enumerate(flat))
+    if not os.path.exists(DFT16_INC) or open(DFT16_INC).read() != text:
+        with open(DFT16_INC, "w") as f:
+            f.write(text)
+    return DFT16_INC
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -61,7 +91,7 @@ def _stale(target, deps):
 
 
 def needs_build():
-    if not os.path.exists(TWIDDLE_INC):
+    if not os.path.exists(TWIDDLE_INC) or not os.path.exists(os.path.join(CSRC, "_gen_dft16_f16.inc")):
         return True
     deps = list(COMMON_DEPS)
     for name, _flags, extra in UNITS:
@@ -74,6 +104,7 @@ def build_native(force=False, verbose=False, defines=(), lib=None, obj_tag=""):
     `defines` / `lib` / `obj_tag`: a variant library beside the product one (tools/ A/B measurements), e.g.
     defines=("-DSUSHI_FFT_LOGN=13",), lib=".../libsushi_hip_n13.so", obj_tag="_n13"."""
     write_twiddles()
+    write_dft16_operands()
     lib = lib or LIB
     if not force and not defines and not needs_build():
         return lib

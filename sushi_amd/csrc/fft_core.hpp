@@ -256,6 +256,48 @@ SUSHI_HHD int wslot_of_bin(int f) {
     return (((((w * 4 + (d1 >> 2)) << 6) + 16 * d3 + d2) << 1) + ((d1 >> 1) & 1)) * 2 + (d1 & 1);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// First pass of the wave plan on the matrix pipe (inverse transforms whose input arrives as packed halves).
+//
+// Pass 1 is 64 independent 16-point DFTs per wave (over d1, one per column (d2, d3)): as a matrix product with the data as the
+// A operand of v_mfma_f32_16x16x32_f16,
+//     D[m][n] = sum_k A[m][k] B[k][n],   m = a column of the group, k = (part, d1): 16 real parts then 16 imaginary parts, n = e1,
+// B holding the DFT matrix ([Wr; -Wi] for the real parts of the result, [Wi; Wr] for the imaginary ones; each as the sum of a high
+// and a low half, so that the products are exact to float32), the result lands where the wave plan wants it AFTER its row
+// exchange: lane (d3 = lane >> 4, e1 = lane & 15) holds d2 = 0 .. 15 in registers -- the exchange through the LDS, pass 1's ~170
+// VALU instructions and the unpacking of the halves all go.
+//   A operand of lane l = (q = l >> 4, m = l & 15), group g: the 8 halves k = 8 q .. 8 q + 7 of column (g, m), i.e.
+//       part = q >> 1 (0: real, 1: imaginary), d1 = 8 (q & 1) + j, j = 0 .. 7, of column d2 = 4 g + (m & 3), d3 = m >> 2.
+//   What the lane LOADS is four whole complex bins (a 16-byte entry, as mac_kernel stores them): lanes below 32 the bins
+//       d1 = 8 (q & 1) + 0 .. 3 of their column, lanes l + 32 the bins d1 = 8 (q & 1) + 4 .. 7 of the same column; two v_perm_b32 pairs
+//       and two v_permlane32_swap per entry turn (re, im) x 4 into (re x 8 | im x 8).
+//   D of lane (q', e1), group g, register i: column m = 4 q' + i, i.e. d3 = q', d2 = 4 g + i.
+// Stored spectra are then in THIS load order (mslot_of_bin).
+// ------------------------------------------------------------------------------------------------------------
+// complex index, inside a stored spectrum, of bin f (MFMA load order)
+SUSHI_HHD int mslot_of_bin(int f) {
+    const int n1 = f & 15, n2 = f >> 4;
+    const int d3 = n2 & 3, d2 = (n2 >> 2) & 15, d1 = n2 >> 6;
+    const int g = d2 >> 2, m = (d3 << 2) | (d2 & 3);
+    const int dq = d1 >> 2, t = d1 & 3;                          // the lane pair (l, l + 32) splits a d1 octet in two quads
+    const int q = (dq >> 1) | ((dq & 1) << 1);                   // octet = dq >> 1 = q & 1, upper quad <=> q >> 1
+    return ((((n1 * 4 + g) << 6) + 16 * q + m) << 2) + t;
+}
+// the bin that sub-position t of entry g of thread tid holds when it loads a stored spectrum
+SUSHI_HHD int mbin(int tid, int g, int t) {
+    const int n1 = tid >> 6, l = tid & 63, q = l >> 4, m = l & 15;
+    const int d1 = 8 * (q & 1) + 4 * (q >> 1) + t, d2 = 4 * g + (m & 3), d3 = m >> 2;
+    return n1 + 16 * (64 * d1 + 4 * d2 + d3);
+}
+// B operands of the four products of a group (real parts: high, low; imaginary parts: high, low) for lane l: element j is
+// row k = 8 (l >> 4) + j of column n = l & 15.  Filled by dft16_operand(); the device keeps them in a table.
+SUSHI_HHD double dft16_operand(int form, int l, int j, int dir) {
+    const int k = 8 * (l >> 4) + j, n = l & 15, kk = k & 15, part = k >> 4;
+    const double PI = 3.14159265358979323846;
+    const double wr = __builtin_cos(2.0 * PI * (double)((n * kk) & 15) / 16.0), wi = (double)dir * __builtin_sin(2.0 * PI * (double)((n * kk) & 15) / 16.0);
+    return form == 0 ? (part == 0 ? wr : -wi) : (part == 0 ? wi : wr);       // form 0: real parts of the result, 1: imaginary parts
+}
+
 struct WTwiddles { cpx g2, q3, p4; };
 
 template <int DIR>
@@ -412,6 +454,64 @@ __device__ __forceinline__ void fft_wave(cpx* v, int tid, float* lds, const WTwi
     w_pass3<DIR>(v, tw.q3);                                      // pass 3
     __syncthreads();                                             // every wave is done with its row-exchange floats
     w_wg_store<0>(v, tid, lds);
+    __syncthreads();
+    w_wg_load<0>(v, tid, lds);
+    __syncthreads();
+    w_wg_store<1>(v, tid, lds);
+    __syncthreads();
+    w_wg_load<1>(v, tid, lds);
+    pass_compute<16, WNT, DIR>(v, tw.p4);                        // pass 4
+}
+// The same transform with its first pass on the matrix pipe (header of "First pass ... on the matrix pipe" above).  `yl`: the
+// thread's four 16-byte entries of a spectrum stored in mslot_of_bin order, as loaded; `b`: the lane's DFT-matrix operands.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+struct MfmaB { half8 rh, rl, ih, il; };
+__device__ __forceinline__ MfmaB load_mfma_b(int tid, const uint4v* __restrict__ table) {
+    const int lane = tid & 63;
+    MfmaB b;
+    b.rh = __builtin_bit_cast(half8, table[0 * 64 + lane]);
+    b.rl = __builtin_bit_cast(half8, table[1 * 64 + lane]);
+    b.ih = __builtin_bit_cast(half8, table[2 * 64 + lane]);
+    b.il = __builtin_bit_cast(half8, table[3 * 64 + lane]);
+    return b;
+}
+template <int DIR>
+__device__ __forceinline__ void fft_wave_mfma(const uint4v (&yl)[4], cpx* v, int tid, float* lds, const WTwiddles tw, const MfmaB& b) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        // (re, im) x 4 bins -> re x 8 in the lanes below 32, im x 8 in the lanes above (the other four bins are the partner lane's)
+        unsigned rr01 = __builtin_amdgcn_perm(yl[g][1], yl[g][0], 0x05040100u), rr23 = __builtin_amdgcn_perm(yl[g][3], yl[g][2], 0x05040100u);
+        unsigned ii01 = __builtin_amdgcn_perm(yl[g][1], yl[g][0], 0x07060302u), ii23 = __builtin_amdgcn_perm(yl[g][3], yl[g][2], 0x07060302u);
+        { const auto r = __builtin_amdgcn_permlane32_swap(rr01, ii01, false, false); rr01 = r[0]; ii01 = r[1]; }
+        { const auto r = __builtin_amdgcn_permlane32_swap(rr23, ii23, false, false); rr23 = r[0]; ii23 = r[1]; }
+        const uint4v aw = {rr01, rr23, ii01, ii23};
+        const half8 a = __builtin_bit_cast(half8, aw);
+        const float4v z = {0.f, 0.f, 0.f, 0.f};
+        float4v dr = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b.rh, z, 0, 0, 0);
+        float4v di = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b.ih, z, 0, 0, 0);
+        dr = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b.rl, dr, 0, 0, 0);
+        di = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b.il, di, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[4 * g + i] = cpx{dr[i], di[i]};
+    }
+    pass_compute<16, 16, DIR>(v, tw.g2);                         // pass 2 (twiddle, then the DFTs)
+    auto swap32 = [](float& x, float& y) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+        x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
+    };
+    auto swap16 = [](float& x, float& y) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+        x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
+    };
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { swap32(v[r].x, v[r + 8].x); swap32(v[r].y, v[r + 8].y); }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if ((r & 4) == 0) { swap16(v[r].x, v[r + 4].x); swap16(v[r].y, v[r + 4].y); }
+    w_pass3<DIR>(v, tw.q3);                                      // pass 3
+    w_wg_store<0>(v, tid, lds);                                  // (no wave used the buffer before: no barrier in front)
     __syncthreads();
     w_wg_load<0>(v, tid, lds);
     __syncthreads();

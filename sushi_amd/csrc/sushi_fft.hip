@@ -112,24 +112,23 @@ static_assert(FFT_LOGN == 14 && sushi_fft::W_LDS_FLOATS <= LDS_FLOATS && FT == s
 // over through the LDS (real parts, then imaginary parts; position tid + tid / 64 makes the gather conflict-free) so that
 // the global stores are whole KiB per wave instead of 16-byte pieces 8 KiB apart (pattern spectra are written every run).
 __device__ __forceinline__ void to_load_order(cpx (&v)[sushi_fft::PER], const int tid, float* lds) {
-    constexpr int P = FT + FT / 64;
-    const int src = (tid >> 6) + 64 * (tid & 15) + 16 * ((tid >> 4) & 3);
-    float* out = lds + tid + (tid >> 6);
-    const float* in = lds + src + (src >> 6);
+    // element e of the stored order sits at e + e / 16 + e / 1024 (the producer's scattered stores then spread over the banks);
+    // a thread takes its four runs of four (the entries it will store) back out
+    auto pos = [](const int e) { return e + (e >> 4) + (e >> 10); };
     __syncthreads();                                             // the transform's own use of the buffer is over
 #pragma unroll
-    for (int r = 0; r < sushi_fft::PER; ++r) out[P * r] = v[r].x;
+    for (int r = 0; r < sushi_fft::PER; ++r) lds[pos(sushi_fft::mslot_of_bin(tid + FT * r))] = v[r].x;
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < sushi_fft::PER; ++r) v[r].x = in[P * r];
+    for (int r = 0; r < sushi_fft::PER; ++r) v[r].x = lds[pos(4 * sushi_fft::wslot_uint4(tid, r >> 2) + (r & 3))];
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < sushi_fft::PER; ++r) out[P * r] = v[r].y;
+    for (int r = 0; r < sushi_fft::PER; ++r) lds[pos(sushi_fft::mslot_of_bin(tid + FT * r))] = v[r].y;
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < sushi_fft::PER; ++r) v[r].y = in[P * r];
+    for (int r = 0; r < sushi_fft::PER; ++r) v[r].y = lds[pos(4 * sushi_fft::wslot_uint4(tid, r >> 2) + (r & 3))];
 }
-static_assert(sushi_fft::PER * (FT + FT / 64) <= LDS_FLOATS, "the hand-over fits the transform's buffer");
+static_assert(FN + FN / 16 + FN / 1024 <= LDS_FLOATS, "the hand-over fits the transform's buffer");
 
 // exp(-2*pi*i*n/16384), n = 0..16383, float32 rounded from float64 (generated by sushi_amd/build.py)
 __device__ const float g_twiddle[2 * sushi_fft::TWIDDLE_N] = {
@@ -137,6 +136,14 @@ __device__ const float g_twiddle[2 * sushi_fft::TWIDDLE_N] = {
 };
 
 __device__ __forceinline__ const cpx* twiddles() { return reinterpret_cast<const cpx*>(g_twiddle); }
+
+// B operands of the inverse transform's first pass on the matrix pipe: [product][lane] x 8 halves (generated by sushi_amd/build.py)
+__device__ __attribute__((aligned(16))) const unsigned g_dft16_b[4 * 64 * 4] = {
+#include "_gen_dft16_f16.inc"
+};
+__device__ __forceinline__ sushi_fft::MfmaB dft16_operands(const int tid) {
+    return sushi_fft::load_mfma_b(tid, reinterpret_cast<const sushi_fft::uint4v*>(g_dft16_b));
+}
 
 // ------------------------------------------------------------------------------------------
 // Destination-stream spectra
@@ -573,18 +580,16 @@ __device__ __forceinline__ float ccoeff_kn(float inv_sqrt_m) { return FFT_KE + 8
 // it: one 16-byte load brings four registers, a wave's load instruction one contiguous KiB.  Issued before anything else a
 // workgroup does: the address needs the pair index only, and the search's descriptor and constants (two more dependent
 // loads) are not needed before the epilogue -- with two workgroups per CU every serial hop at a workgroup's start is CU time.
-__device__ __forceinline__ float load_y(cpx (&v)[sushi_fft::PER], const uint2* __restrict__ yin, const int tid) {
+__device__ __forceinline__ float load_y(sushi_fft::uint4v (&yl)[4], const uint2* __restrict__ yin, const int tid) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const uint4* __restrict__ yh = reinterpret_cast<const uint4*>(yin);
+    const sushi_fft::uint4v* __restrict__ yh = reinterpret_cast<const sushi_fft::uint4v*>(yin);
     float q2 = 0.f;                                              // energy of this thread's part of the row (quantisation model)
 #pragma unroll
     for (int u = 0; u < sushi_fft::PER / 4; ++u) {
-        const uint4 q = yh[(((tid >> 6) * 4 + u) << 6) + (tid & 63)];    // registers 4u .. 4u+3: eight halves
-        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+        yl[u] = yh[sushi_fft::wslot_uint4(tid, u)];              // four bins: eight halves, as they go to the matrix pipe
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const h2 h = __builtin_bit_cast(h2, w[j]);
-            v[4 * u + j] = cpx{(float)h.x, (float)h.y};
+            const h2 h = __builtin_bit_cast(h2, yl[u][j]);
             q2 = __builtin_amdgcn_fdot2(h, h, q2, false);                  // |Y(f)|^2 straight from the two halves
         }
     }
@@ -597,7 +602,7 @@ __device__ __forceinline__ float load_y(cpx (&v)[sushi_fft::PER], const uint2* _
 // METHOD 1  score = 1 - (sum T I - sum I * mean T) / sqrt(sum (T - mean T)^2 * (sum I^2 - (sum I)^2 / M)): the same cross
 //           term with the same bound; the window sums come from the stream's second relative prefix (srel / sbase).
 template <int METHOD>
-__device__ __forceinline__ void score_pair(const IfftArgs& a, cpx (&v)[sushi_fft::PER], const SearchDesc& sd,
+__device__ __forceinline__ void score_pair(const IfftArgs& a, const sushi_fft::uint4v (&yl)[4], const sushi_fft::MfmaB& mb, const SearchDesc& sd,
                                            const TemplConsts& tc, const int64_t pairI, float* lds, const int tid,
                                            const sushi_fft::WTwiddles& tw, PairScores& ps, int& plo_out, int& phi_out,
                                            float& zn_out, float& znc_out) {
@@ -716,7 +721,8 @@ __device__ __forceinline__ void score_pair(const IfftArgs& a, cpx (&v)[sushi_fft
         int64_t b0 = kA < a.nb ? kA : a.nb;
         span_start1 = a.sbase[b0];
     }
-    sushi_fft::fft_wave<1>(v, tid, lds, tw);
+    cpx v[sushi_fft::PER];
+    sushi_fft::fft_wave_mfma<1>(yl, v, tid, lds, tw, mb);
     // keep the window loads below the last pass: hoisted above it (the scheduler's preference) they do not
     // fit the register budget next to the radix-16 butterflies and get spilled to scratch one by one.
     // `after_fft` is an opaque zero that the asm "computes" from the needed outputs; added to the load
@@ -916,8 +922,9 @@ void ifft_kernel(IfftArgs a) {
     // destination stream run back to back on one XCD, so that the prefix-sum lines they share are fetched into that
     // XCD's L2 once instead of once per search
     const int pr = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
-    cpx v[sushi_fft::PER];
-    const float q2 = load_y(v, a.y + (size_t)pr * (FN / 2), tid);      // in flight while the descriptors below arrive
+    sushi_fft::uint4v yl[4];
+    const float q2 = load_y(yl, a.y + (size_t)pr * (FN / 2), tid);     // in flight while the descriptors below arrive
+    const sushi_fft::MfmaB mb = dft16_operands(tid);
     const sushi_fft::WTwiddles tw = sushi_fft::load_wtwiddles<1>(tid, twiddles());
     const int lane = tid & 63;
     {
@@ -940,7 +947,7 @@ void ifft_kernel(IfftArgs a) {
     PairScores ps;
     int plo, phi;
     float zn, zn_c;
-    score_pair<METHOD>(a, v, sd, tc, lay.pair0 + i, lds, tid, tw, ps, plo, phi, zn, zn_c);
+    score_pair<METHOD>(a, yl, mb, sd, tc, lay.pair0 + i, lds, tid, tw, ps, plo, phi, zn, zn_c);
     // minimum of the pair and the largest 1/|window| (error bound): 32-bit wave reductions, then one LDS atomic each per
     // wave and ONE barrier -- the workgroup's tail is serial time on a CU that holds two workgroups
     const float wmin = wave_min_f32(ps.best), wrs = wave_max_f32(ps.max_rs);
@@ -1023,6 +1030,7 @@ void collect_kernel(IfftArgs a) {
     if (n_flagged == 0) return;
     const int tid = threadIdx.x;
     const sushi_fft::WTwiddles tw = sushi_fft::load_wtwiddles<1>(tid, twiddles());
+    const sushi_fft::MfmaB mb = dft16_operands(tid);
     const int lane = tid & 63, wave = tid >> 6;
     for (int f = blockIdx.y; f < n_flagged; f += gridDim.y) {
         const int s_idx = a.flag_list[f];                                  // global search index
@@ -1044,11 +1052,11 @@ void collect_kernel(IfftArgs a) {
             if (!everything) {
                 PairScores ps;
                 float zn;
-                cpx v[sushi_fft::PER];
-                const float q2 = load_y(v, a.y + (size_t)pr * (FN / 2), tid);
+                sushi_fft::uint4v yl[4];
+                const float q2 = load_y(yl, a.y + (size_t)pr * (FN / 2), tid);
                 const float qw = wave_sum_f32(q2);
                 float zn_c;
-                score_pair<METHOD>(a, v, sd, tc, lay.pair0 + i, lds, tid, tw, ps, plo, phi, zn, zn_c);
+                score_pair<METHOD>(a, yl, mb, sd, tc, lay.pair0 + i, lds, tid, tw, ps, plo, phi, zn, zn_c);
                 float wrs = ps.max_rs;
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) wrs = fmaxf(wrs, __shfl_down(wrs, d, 64));
@@ -1396,7 +1404,7 @@ int sushi_hip_fft_size(void) { return FN; }
 
 int sushi_hip_fft_block(void) { return FFT_SEG; }
 
-int sushi_hip_fft_slot_of_bin(int bin) { return (bin < 0 || bin >= FN) ? -1 : sushi_fft::wslot_of_bin(bin); }
+int sushi_hip_fft_slot_of_bin(int bin) { return (bin < 0 || bin >= FN) ? -1 : sushi_fft::mslot_of_bin(bin); }
 
 size_t sushi_hip_stream_spectra_bytes(int64_t n) {
     return n <= 0 ? 0 : (size_t)((n + FFT_SEG - 1) / FFT_SEG + 1) * ROW_BYTES;

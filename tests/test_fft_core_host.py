@@ -29,6 +29,14 @@ def test_mac_ring_on_host(tmp_path):
     assert float(r.stdout.split()[0]) < 1e-5
 
 
+def test_mfma_first_pass_on_host(tmp_path):
+    """The inverse transform with its first pass on the matrix pipe, emulated lane by lane (stored order -> 16-byte loads ->
+    v_perm_b32 / v_permlane32_swap -> v_mfma_f32_16x16x32_f16 -> the wave plan's passes 2 .. 4) against a float64 FFT."""
+    r = _build_and_run(tmp_path, "host_mfma_check")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert float(r.stdout.split()[0]) < 8e-7
+
+
 def test_twiddle_table_is_correctly_rounded():
     from sushi_amd import build
     path = build.write_twiddles()
