@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SUSHI_HIP_ABI_VERSION 8   /* 8: block spectra are packed halves (sushi_hip_stream_spectra_bytes, SUSHI_HIP_VIEW_SPECTRA) */
+#define SUSHI_HIP_ABI_VERSION 9   /* 9: SushiHipBatchDiag.audited (16 audited non-candidate positions per search) */
 
 #if defined(__GNUC__)
 #define SUSHI_HIP_API __attribute__((visibility("default")))
@@ -75,7 +75,8 @@ SUSHI_HIP_API int sushi_hip_device_ok(void);
  *              integral cv2 builds per call; exact for uint8)
  *   urel[n+1]  float32 + base[nb+1] float64, nb = ceil(n / B), B = sushi_hip_fft_block():
  *              s2[e] = base[e / B] + urel[e]   (the window energies in the cheap form the FFT scoring reads)
- *   srel[n+1]  float32 + base1[nb+1] float64: the same for s1 (window sums of TM_CCOEFF_NORMED)
+ *   usrel[n+1][2] float32 + base1[nb+1] float64: (urel[e], srel[e]) interleaved, srel = the same for s1 (the window sums of
+ *              TM_CCOEFF_NORMED, which reads both prefixes with one 8-byte load per window end)
  *   spectra    (searchable streams only; sushi_hip_stream_add_spectra attaches them later)  for every block
  *              j = 0 .. nb-1 the N-point complex DFT, N = sushi_hip_fft_size(), H = N - B, of
  *                  (x - mean)[jB .. jB+N) + i * (x - mean)[jB+H .. jB+H+N)         (zeros past the end)
@@ -103,7 +104,7 @@ SUSHI_HIP_API int sushi_hip_stream_add_spectra(SushiHipStream* stream, void* mem
 #define SUSHI_HIP_VIEW_UREL 3
 #define SUSHI_HIP_VIEW_BASE 4
 #define SUSHI_HIP_VIEW_SPECTRA 5
-#define SUSHI_HIP_VIEW_SREL 6     /* float32[n+1]: s1[e] = base1[e / B] + srel[e] (TM_CCOEFF_NORMED's window sums on the FFT path) */
+#define SUSHI_HIP_VIEW_USREL 6    /* float32[n+1][2]: (urel[e], srel[e]), s1[e] = base1[e / B] + srel[e] (TM_CCOEFF_NORMED's window sums on the FFT path) */
 #define SUSHI_HIP_VIEW_BASE1 7    /* float64[nb+1] */
 SUSHI_HIP_API int sushi_hip_stream_view(const SushiHipStream* stream, int which, const void** ptr_dev, size_t* bytes);
 SUSHI_HIP_API void sushi_hip_stream_destroy(SushiHipStream* stream);
@@ -141,9 +142,13 @@ typedef struct SushiHipBatchDiag {
     int64_t candidates;       /* listed candidate positions */
     float max_bound_ratio;    /* max over the exactly evaluated candidates of |f32 score - exact score| / the pair's
                                  modelled error bound (without the delta/2 floor); < 1 or the search went to all_positions */
-    float max_bound_ratio_noncandidate; /* the same over one pseudo-random NON-candidate position per search (the pair's
-                                 "audit" position, picked by a hash): the error model checked where it was not already
-                                 believed.  A violation there sends the search to all_positions too. */
+    float max_bound_ratio_noncandidate; /* the same over the AUDITED positions: per search the audit runs (4 consecutive
+                                 positions at a hashed place) of 4 hashed pairs spread over the window -- up to 16 positions that
+                                 were NOT selected, evaluated exactly and held to the bound they were ranked with: the error
+                                 model checked where it was not already believed.  A violation there sends the search to
+                                 all_positions too.  The bound is a statistical model (8 standard deviations of the packed-half
+                                 roundings), not a worst-case proof: this field is what watches it. */
+    int64_t audited;          /* audited non-candidate positions of the run */
 } SushiHipBatchDiag;
 
 typedef struct SushiHipBatch SushiHipBatch;

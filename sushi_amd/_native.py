@@ -19,9 +19,9 @@ U8, F32 = 0, 1
 PATH_FFT, PATH_DIRECT = 0, 1
 METHOD_SQDIFF_NORMED, METHOD_CCOEFF_NORMED = 0, 1       # cv2.TM_SQDIFF_NORMED + argmin (wav.py:185-186) | cv2.TM_CCOEFF_NORMED + argmax
 METHODS = {"sqdiff_normed": METHOD_SQDIFF_NORMED, "ccoeff_normed": METHOD_CCOEFF_NORMED}
-VIEW_XC, VIEW_S1, VIEW_S2, VIEW_UREL, VIEW_BASE, VIEW_SPECTRA, VIEW_SREL, VIEW_BASE1 = range(8)
+VIEW_XC, VIEW_S1, VIEW_S2, VIEW_UREL, VIEW_BASE, VIEW_SPECTRA, VIEW_USREL, VIEW_BASE1 = range(8)
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 NSTAGES = 5
 STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish")
 STAGE_KERNELS = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "ifft_kernel", "refine": "refine_kernel",
@@ -42,7 +42,7 @@ class BatchInfo(ctypes.Structure):
 class BatchDiag(ctypes.Structure):
     _fields_ = [("flagged", ctypes.c_int32), ("all_positions", ctypes.c_int32), ("tiles_dense", ctypes.c_int64),
                 ("tiles_sparse", ctypes.c_int64), ("candidates", ctypes.c_int64), ("max_bound_ratio", ctypes.c_float),
-                ("max_bound_ratio_noncandidate", ctypes.c_float)]
+                ("max_bound_ratio_noncandidate", ctypes.c_float), ("audited", ctypes.c_int64)]
 
 
 _lib = None

@@ -22,8 +22,11 @@ constexpr int FFT_HOP = FFT_SEG;                   // also the block size of the
 constexpr int FFT_VB = FFT_N / FFT_SEG - 1;        // valid blocks per half of a pair: 3
 constexpr int FFT_H = FFT_VB * FFT_SEG;            // result positions per half
 constexpr int FFT_STEP = 2 * FFT_VB;               // blocks between consecutive pairs
-constexpr int FFT_CAND = 8;                        // candidate slots per block pair (+ overflow marker + error bound + audit position)
-constexpr int FFT_ROW = FFT_CAND + 3;              // 64-bit entries per pair in the candidate array
+constexpr int FFT_CAND = 8;                        // candidate slots per block pair (+ overflow marker + error bound + audit positions)
+constexpr int FFT_AUDIT = 4;                       // audit positions a pair leaves: a run of consecutive positions (one exact evaluation's worth of loads)
+constexpr int FFT_ROW = 16;                        // 64-bit entries per pair in the candidate array: a 128-byte line
+static_assert(FFT_CAND + 2 + FFT_AUDIT <= FFT_ROW, "candidates, overflow marker, error bound, audit run");
+constexpr int AUDIT_PAIRS = 4;                     // pairs per search whose audit run refine_kernel evaluates exactly: 16 non-candidate positions
 constexpr int TILE = 1024;                         // positions per exact-evaluation tile (aligned to the absolute grid)
 constexpr int TILES_PER_PAIR = 2 * FFT_H / TILE;
 // error model of the f32 FFT stage: |corr_f32 - corr| <= FFT_KE * 2^-24 * |T| * |Z|, Z = the samples that enter the

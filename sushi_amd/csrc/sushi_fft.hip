@@ -539,7 +539,7 @@ struct IfftArgs {
     const TemplConsts* tconst;        // [searches of the sub-batch]
     const float* urel;                // dst stream: prefix of the uncentred squares relative to its block's base
     const double* ubase;              // dst stream: those block bases [nb + 1]
-    const float* srel;                // dst stream: prefix of the samples relative to its block's base (TM_CCOEFF_NORMED)
+    const float* usrel;               // dst stream: (urel, prefix of the samples relative to its block's base) interleaved (TM_CCOEFF_NORMED)
     const double* sbase;              // dst stream: those block bases [nb + 1]
     int64_t nb;                       // blocks of the dst stream
     // collection pass only
@@ -607,7 +607,7 @@ __device__ __forceinline__ void score_pair(const IfftArgs& a, const sushi_fft::u
                                            const sushi_fft::WTwiddles& tw, PairScores& ps, int& plo_out, int& phi_out,
                                            float& zn_out, float& znc_out) {
     constexpr bool CC = METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED;
-    constexpr int GQM = GQ;                                      // (GQ / 2 for METHOD 1 was tried: more scratch, not less)
+    constexpr int GQM = CC ? GQ / 2 : GQ;                        // METHOD 1 holds two values per window end: half as many positions per group
     constexpr int NG = 2 * HPT / GQM;
     const int M = sd.tmpl_len;
     const int64_t P = sd.n_pos;
@@ -626,8 +626,9 @@ __device__ __forceinline__ void score_pair(const IfftArgs& a, const sushi_fft::u
     const int limM = (int)(roomM < 2 * FH - 1 ? roomM : 2 * FH - 1);     // may be negative
     const float* __restrict__ rMb = limM < 0 ? r0b : r0b + M;
     const int limMc = limM < 0 ? 0 : limM;
-    const float* __restrict__ s0b = a.srel + qbase;                      // (METHOD 1) the same for the sums of the samples
-    const float* __restrict__ sMb = limM < 0 ? s0b : s0b + M;
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const f2v* __restrict__ s0b = reinterpret_cast<const f2v*>(a.usrel) + qbase;      // (METHOD 1) both prefixes, interleaved: one 8-byte load per end
+    const f2v* __restrict__ sMb = limM < 0 ? s0b : s0b + M;
     float ra[GQM], rb[GQM], ra_n[GQM], rb_n[GQM];
     float sa[CC ? GQM : 1], sb_[CC ? GQM : 1], sa_n[CC ? GQM : 1], sb_n[CC ? GQM : 1];
     unsigned after_fft = 0;
@@ -654,27 +655,36 @@ __device__ __forceinline__ void score_pair(const IfftArgs& a, const sushi_fft::u
             if (INTERIOR) {
                 // each load's base is an opaque scalar: left visible, base + lane offset is shared between the loads and
                 // every displacement past the instruction's 4 KB immediate costs a 64-bit vector add
-                typedef const __attribute__((address_space(1))) float* gptr;
-                gptr pa = (gptr)(r0b + FT * r + half * FH);
-                gptr pb = (gptr)(rMb + FT * r + half * FH);
-                asm volatile("" : "+s"(pa));
-                asm volatile("" : "+s"(pb));
-                xa[q] = pa[(unsigned)(tid + after_fft) & 0x7fffu];
-                xb[q] = pb[(unsigned)(tid + after_fft) & 0x7fffu];
                 if (CC) {
-                    gptr qa = (gptr)(s0b + FT * r + half * FH);
-                    gptr qb = (gptr)(sMb + FT * r + half * FH);
+                    typedef const __attribute__((address_space(1))) f2v* gptr2;
+                    gptr2 qa = (gptr2)(s0b + FT * r + half * FH);
+                    gptr2 qb = (gptr2)(sMb + FT * r + half * FH);
                     asm volatile("" : "+s"(qa));
                     asm volatile("" : "+s"(qb));
-                    ya[q] = qa[(unsigned)(tid + after_fft) & 0x7fffu];
-                    yb[q] = qb[(unsigned)(tid + after_fft) & 0x7fffu];
+                    const f2v va = qa[(unsigned)(tid + after_fft) & 0x7fffu];
+                    const f2v vb = qb[(unsigned)(tid + after_fft) & 0x7fffu];
+                    xa[q] = va.x; ya[q] = va.y;
+                    xb[q] = vb.x; yb[q] = vb.y;
+                } else {
+                    typedef const __attribute__((address_space(1))) float* gptr;
+                    gptr pa = (gptr)(r0b + FT * r + half * FH);
+                    gptr pb = (gptr)(rMb + FT * r + half * FH);
+                    asm volatile("" : "+s"(pa));
+                    asm volatile("" : "+s"(pb));
+                    xa[q] = pa[(unsigned)(tid + after_fft) & 0x7fffu];
+                    xb[q] = pb[(unsigned)(tid + after_fft) & 0x7fffu];
                 }
             } else {
                 const unsigned oa = (((unsigned)(pos <= lim0 ? pos : lim0)) + after_fft) & 0x7fffu;
                 const unsigned ob = (((unsigned)(pos <= limM ? pos : limMc)) + after_fft) & 0x7fffu;
-                xa[q] = r0b[oa];
-                xb[q] = rMb[ob];
-                if (CC) { ya[q] = s0b[oa]; yb[q] = sMb[ob]; }
+                if (CC) {
+                    const f2v va = s0b[oa], vb = sMb[ob];
+                    xa[q] = va.x; ya[q] = va.y;
+                    xb[q] = vb.x; yb[q] = vb.y;
+                } else {
+                    xa[q] = r0b[oa];
+                    xb[q] = rMb[ob];
+                }
             }
         }
     };
@@ -867,11 +877,13 @@ __device__ __forceinline__ void score_pair(const IfftArgs& a, const sushi_fft::u
 // METHOD 1: numerator error / (|T_c| |W_c|) + the relative error of 1 / sqrt(variance sum) (the score is <= 1 in size)
 template <int METHOD>
 __device__ __forceinline__ float pair_error_model(float zn, float zn_c, float max_rs, const TemplConsts& tc, float q2,
-                                                  float inv_scale) {
+                                                  float inv_scale, int mac_passes) {
     const float eps = 5.9604645e-8f;                             // 2^-24
     // quantisation of the Y row: every stored half is off by <= 2^-11 of its size (round to nearest), independently; the
     // inverse transform sums N of them: variance (2^-22 / 3) * sum |Y(f)|^2 (+ the subnormal floor), Y_KQ deviations
-    const float sigma_y = sqrtf(q2 * 2.3841858e-7f + (float)FN * 1.2e-15f) * inv_scale;   // 3 x 2^-22 / 3: the row's own rounding + its two factors' (module header)
+    // (2^-22 / 3) x (the row's own rounding, once per accumulating pass of mac_long_kernel: a pattern of more than MAC_SMAX_LONG
+    // segments re-rounds the partial row every pass; + its two factors' roundings: module header)
+    const float sigma_y = sqrtf(q2 * (7.9472862e-8f * (float)(2 + mac_passes)) + (float)FN * 1.2e-15f) * inv_scale;
     if (METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED) {
         const float ism = sqrtf(tc.inv_m);
         const float z = fmaxf(zn, zn_c);
@@ -961,7 +973,8 @@ void ifft_kernel(IfftArgs a) {
     const bool have_min = lmin_s < __builtin_inff();
     static_assert(FT / 64 == 16, "one row of lanes reads the sixteen wave sums");
     const float qmax = row_reduce_f32(red_q[lane & 15], [](float a, float b) { return fmaxf(a, b); });
-    const float e_model = pair_error_model<METHOD>(zn, zn_c, rs_max, tc, (float)(FT / 64) * qmax, tc.inv_scale);
+    const int mac_passes = (lay.n_seg + MAC_SMAX_LONG - 1) / MAC_SMAX_LONG;
+    const float e_model = pair_error_model<METHOD>(zn, zn_c, rs_max, tc, (float)(FT / 64) * qmax, tc.inv_scale, mac_passes);
     const float e_pair = fmaxf(0.5f * a.delta, e_model);
     // positions leave this kernel relative to the search's window: p = (pair's first sample + pos) - win_start
     const int64_t shift = (lay.pair0 + i) * (int64_t)FFT_STEP * FFT_SEG - sd.win_start;
@@ -1000,17 +1013,19 @@ void ifft_kernel(IfftArgs a) {
         if (lowest != 0x7fffffff)
             atomicMin(a.gkeys + a.first_search + k, make_key(lmin_s + e_pair, (unsigned)((int64_t)lowest + shift)));
     }
-    // the pair's audit position: one pseudo-random position (by a hash of the pair index) leaves with its plain f32
-    // score whether or not it is a candidate; refine_kernel evaluates one of them per search exactly
+    // the pair's audit run: FFT_AUDIT consecutive positions at a pseudo-random place (a hash of the pair index) leave with their
+    // plain f32 scores whether or not they are candidates; refine_kernel evaluates the runs of AUDIT_PAIRS pairs per search
+    // exactly (consecutive positions: their windows are one another's but for a sample, so a run costs the loads of ONE position)
     {
         const unsigned h = ((unsigned)(a.sub_first_pair + pr) * 2654435761u) >> 7;
-        const int pos_a = (int)(h % (unsigned)(2 * FH));
-        if (tid == pos_a % FT) {
+        const int pos_a = FFT_AUDIT * (int)(h % (unsigned)(2 * FH / FFT_AUDIT));      // the run's first position; FT % FFT_AUDIT == 0: one r, one half
+        const int j = tid - pos_a % FT;
+        if (j >= 0 && j < FFT_AUDIT) {
             const int qa = (pos_a / FH) * HPT + (pos_a % FH) / FT;
             float sc = __builtin_inff();
 #pragma unroll
             for (int q = 0; q < 2 * HPT; ++q) sc = q == qa ? ps.scores[q] : sc;
-            if (sc >= 0.f && sc < __builtin_inff()) cout[FFT_CAND + 2] = make_key(sc, (unsigned)((int64_t)pos_a + shift));
+            if (sc >= 0.f && sc < __builtin_inff()) cout[FFT_CAND + 2 + j] = make_key(sc, (unsigned)((int64_t)(pos_a + j) + shift));
         }
     }
 }
@@ -1024,14 +1039,13 @@ template <int METHOD>
 __global__ __launch_bounds__(FT, 8)
 void collect_kernel(IfftArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    __shared__ float redr[FT / 64], redq[FT / 64];
     __shared__ int tcnt[TILES_PER_PAIR], toff[TILES_PER_PAIR], tfill[TILES_PER_PAIR];
     const int n_flagged = *a.sub_flagged;
     if (n_flagged == 0) return;
     const int tid = threadIdx.x;
     const sushi_fft::WTwiddles tw = sushi_fft::load_wtwiddles<1>(tid, twiddles());
     const sushi_fft::MfmaB mb = dft16_operands(tid);
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
     for (int f = blockIdx.y; f < n_flagged; f += gridDim.y) {
         const int s_idx = a.flag_list[f];                                  // global search index
         const int k = s_idx - a.first_search;
@@ -1043,6 +1057,9 @@ void collect_kernel(IfftArgs a) {
         const float U = a.gkeys[s_idx] == NO_KEY ? 4.0f : key_score(a.gkeys[s_idx]);
         for (int i = blockIdx.x; i < lay.n_pairs; i += gridDim.x) {
             const int pr = sd.first_pair - a.sub_first_pair + i;
+            // ifft_kernel left the smallest lower bound of this pair's positions: above the search's threshold, the pair holds no
+            // candidate and its transform need not be redone (workgroup-uniform)
+            if (!everything && !(a.pair_lb[pr] <= U)) continue;
             const int64_t qbase = (lay.pair0 + i) * (int64_t)FFT_STEP * FFT_SEG;
             const int64_t rel0 = qbase - sd.win_start;                     // position (relative to the window) of pos 0
             __syncthreads();                                               // previous item's shared state is consumed
@@ -1051,22 +1068,12 @@ void collect_kernel(IfftArgs a) {
             int plo = 0, phi = 0;
             if (!everything) {
                 PairScores ps;
-                float zn;
+                float zn, zn_c;
                 sushi_fft::uint4v yl[4];
-                const float q2 = load_y(yl, a.y + (size_t)pr * (FN / 2), tid);
-                const float qw = wave_sum_f32(q2);
-                float zn_c;
+                (void)load_y(yl, a.y + (size_t)pr * (FN / 2), tid);
                 score_pair<METHOD>(a, yl, mb, sd, tc, lay.pair0 + i, lds, tid, tw, ps, plo, phi, zn, zn_c);
-                float wrs = ps.max_rs;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) wrs = fmaxf(wrs, __shfl_down(wrs, d, 64));
-                if (lane == 0) { redr[wave] = wrs; redq[wave] = qw; }
-                __syncthreads();
-                float rs_max = redr[0], qmax = redq[0];
-#pragma unroll
-                for (int ww = 1; ww < FT / 64; ++ww) { rs_max = fmaxf(rs_max, redr[ww]); qmax = fmaxf(qmax, redq[ww]); }
-                const float e_pair = fmaxf(0.5f * a.delta,
-                                           pair_error_model<METHOD>(zn, zn_c, rs_max, tc, (float)(FT / 64) * qmax, tc.inv_scale));
+                // the bound the pair was ranked with, as ifft_kernel stored it (the same scores again, bit for bit)
+                const float e_pair = __uint_as_float((unsigned)(a.cand[(size_t)pr * FFT_ROW + FFT_CAND + 1] & 0xffffffffull));
 #pragma unroll
                 for (int q = 0; q < 2 * HPT; ++q) {
                     const bool c = fmaxf(ps.scores[q] - e_pair, 0.f) <= U;              // invalid positions hold +inf, uncertain ones -1
@@ -1620,7 +1627,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         ia.sub_first_pair = sbt.first_pair; ia.dst_len = dst->n; ia.delta = (float)delta; ia.cand = cand; ia.pair_lb = pair_lb; ia.gkeys = gkeys;
         ia.pairmap = pairmap; ia.tconst = tconst; ia.order = order + sbt.first_pair;
         ia.urel = dst->urel; ia.nb = dst->blocks; ia.ubase = dst->base;
-        ia.srel = dst->srel; ia.sbase = dst->base + (dst->blocks + 1);
+        ia.usrel = dst->usrel; ia.sbase = dst->base + (dst->blocks + 1);
         ia.flags = flags; ia.flag_list = flag_list; ia.sub_flagged = sub_flagged; ia.tiles = tiles; ia.candbuf = candbuf;
         ia.cand_cap = (int)cand_capacity(sbt.pairs); ia.counters = counters;
         if (b->method == SUSHI_HIP_METHOD_CCOEFF_NORMED)
@@ -1676,6 +1683,7 @@ int sushi_hip_batch_diagnostics(SushiHipBatch* b, SushiHipBatchDiag* diag, float
     diag->candidates = (int64_t)c.candidates;
     memcpy(&diag->max_bound_ratio, &c.max_ratio_bits, sizeof(float));
     memcpy(&diag->max_bound_ratio_noncandidate, &c.max_ratio_audit_bits, sizeof(float));
+    diag->audited = (int64_t)c.audited;
     std::vector<int32_t> fl((size_t)b->n);
     if (hipMemcpy(fl.data(), b->mem + b->lay.flags, (size_t)b->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
         return SUSHI_HIP_ELAUNCH;

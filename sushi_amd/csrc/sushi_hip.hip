@@ -249,43 +249,78 @@ template <typename T> struct WideLoad;
 template <> struct WideLoad<float> { static constexpr int N = 4; struct __attribute__((packed, aligned(4))) V { float v[4]; }; };
 template <> struct WideLoad<uint8_t> { static constexpr int N = 16; struct __attribute__((packed, aligned(1))) V { uint8_t v[16]; }; };
 
-template <typename T>
-__device__ __forceinline__ double chunk_dot(const T* __restrict__ t, const T* __restrict__ w, int mc) {
+// NT tasks of one search over one chunk of the pattern: a task is FFT_AUDIT consecutive positions from its own window pointer
+// on (a candidate is a task whose first position is the one that counts).  Position q of a task sees the window w + q, so a
+// step's window samples serve all of a task's positions, and the pattern samples serve all tasks: per step K pattern loads and
+// K window loads per task (the last window vector of a step is the first of the next).  Every position keeps its own chain in
+// the canonical order -- one fused multiply-add per sample, samples in order -- so its value does not depend on what it was
+// bundled with.  A thread walks its own chunk: neighbouring lanes read 2 KB apart, every load instruction touches 64 lines
+// whatever its width (which is what this stage's time consists of: fewer, wider instructions); the loads of step i + 1 are
+// issued before the additions of step i.  room[i]: window elements readable from w[i] on.
+template <typename T, int NT>
+__device__ __forceinline__ void chunk_bundle(const T* __restrict__ t, const T* const (&w)[NT], const int mc,
+                                             const int64_t (&room)[NT], double (&acc)[NT][FFT_AUDIT]) {
     typedef typename WideLoad<T>::V V;
     constexpr int N = WideLoad<T>::N;
     constexpr int K = N >= 16 ? 1 : 2;                   // a step = 16 uint8 / 8 float32 samples
     constexpr int STEP = K * N;
-    double acc = 0.0;
-    int m = 0;
-    // A thread's chunk is a chain of dependent steps, each waiting for memory that nobody else has touched (neighbouring lanes
-    // read 2 KB apart): the loads of step i + 1 are issued before the additions of step i (the chain was 64 memory round trips
-    // long per chunk and what refine_kernel's time consisted of); the order of the additions is untouched.
-    V a[K], b[K], an[K], bn[K];
-    const int steps = mc / STEP;
+    static_assert(FFT_AUDIT - 1 <= N, "a step's overhang is one more vector");
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int q = 0; q < FFT_AUDIT; ++q) acc[i][q] = 0.0;
+    // whole steps whose window loads (this step's K + 1 vectors, the next step's K) stay inside every task's room
+    int steps = mc / STEP;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int64_t fit = room[i] >= (int64_t)(STEP + N) ? (room[i] - N) / STEP : 0;
+        steps = fit < (int64_t)steps ? (int)fit : steps;
+    }
+    V a[K], an[K], b[NT][K + 1], bn[NT][K];
     if (steps > 0) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            a[j] = *reinterpret_cast<const V*>(t + N * j);
-            b[j] = *reinterpret_cast<const V*>(w + N * j);
+        for (int j = 0; j < K; ++j) a[j] = *reinterpret_cast<const V*>(t + N * j);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < K + 1; ++j) b[i][j] = *reinterpret_cast<const V*>(w[i] + N * j);
+    }
+    for (int s = 0; s < steps; ++s) {
+        const int mn = (s + 1 < steps ? s + 1 : s) * STEP;          // (the last step re-requests itself: unconditional loads)
+#pragma unroll
+        for (int j = 0; j < K; ++j) an[j] = *reinterpret_cast<const V*>(t + mn + N * j);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < K; ++j) bn[i][j] = *reinterpret_cast<const V*>(w[i] + mn + N * (j + 1));
+#pragma unroll
+        for (int e = 0; e < STEP; ++e) {
+            const double te = (double)a[e / N].v[e % N];
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int q = 0; q < FFT_AUDIT; ++q)
+                    acc[i][q] = __builtin_fma(te, (double)b[i][(e + q) / N].v[(e + q) % N], acc[i][q]);
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) a[j] = an[j];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            b[i][0] = b[i][K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) b[i][j + 1] = bn[i][j];
         }
     }
-    for (int i = 0; i < steps; ++i) {
-        const int mn = (i + 1 < steps ? i + 1 : i) * STEP;          // (the last step re-requests itself: unconditional loads)
+    for (int m = steps * STEP; m < mc; ++m) {
+        const double te = (double)t[m];
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            an[j] = *reinterpret_cast<const V*>(t + mn + N * j);
-            bn[j] = *reinterpret_cast<const V*>(w + mn + N * j);
-        }
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-#pragma unroll
-            for (int e = 0; e < N; ++e) acc = __builtin_fma((double)a[j].v[e], (double)b[j].v[e], acc);
-        }
-#pragma unroll
-        for (int j = 0; j < K; ++j) { a[j] = an[j]; b[j] = bn[j]; }
+            for (int q = 0; q < FFT_AUDIT; ++q) {
+                const int64_t x = (int64_t)m + q < room[i] ? (int64_t)m + q : room[i] - 1;     // (past the stream: a position nobody reads)
+                acc[i][q] = __builtin_fma(te, (double)w[i][x], acc[i][q]);
+            }
     }
-    for (m = steps * STEP; m < mc; ++m) acc = __builtin_fma((double)t[m], (double)w[m], acc);
-    return acc;
 }
 
 // Exact evaluation of the tiles collect_kernel listed: every valid position of a dense tile (a thread owns four
@@ -399,13 +434,20 @@ __global__ void unpack_keys_kernel(const unsigned long long* __restrict__ keys, 
 // search, which is then evaluated at every position (flag 2).  One workgroup per search.
 // ------------------------------------------------------------------------------------------
 constexpr int RCAP = 128;
+constexpr int RAUD = AUDIT_PAIRS * FFT_AUDIT;     // audited non-candidate positions per search
+constexpr int RENT = RCAP + RAUD;                // list entries: candidates, then audit positions
+constexpr int RB = 1 + AUDIT_PAIRS;              // tasks per bundle: the usual search is one candidate and AUDIT_PAIRS audit runs
+constexpr int REFINE_THREADS = 128;              // one thread per 512-sample chunk of the pattern: 5.4 s at 12 kHz in one pass
 
-// `n` listed entries; entry `audit_k` (or -1) is not a candidate but the pair's audit position with its plain f32 score:
-// it is evaluated like the others and only checked against the bound (the two-sided check of the error model).
+// Entries [0, n_cand) of the list are candidates; entries [n_cand, n_all) are audit positions: NOT selected, with their plain
+// f32 scores, evaluated like the others and only checked against the bound (the two-sided check of the error model).
+// Work is handed out as tasks: one candidate, one audit position, or a whole audit run of FFT_AUDIT consecutive positions
+// (`tent` = first entry, `tlen` = entries).
 template <typename T>
 __device__ __forceinline__ void refine_body(const RefineParams& a, const int s_idx, const SearchDesc& sd,
                                             const unsigned long long* list, const int* lpair,
-                                            const unsigned long long* rows, const int n, const int audit_k, double* part,
+                                            const unsigned long long* rows, const int n_cand, const int n_all,
+                                            const short* tent, const short* tlen, const int n_tasks, double* part,
                                             unsigned long long* rkey, float* rerr, int* violated, unsigned* wg_ratio) {
     const int tid = threadIdx.x;
     const int M = sd.tmpl_len;
@@ -433,7 +475,7 @@ __device__ __forceinline__ void refine_body(const RefineParams& a, const int s_i
         const float e_model = __uint_as_float((unsigned)(eb >> 32));
         const float lb = key_score(list[k]);
         float err = 0.f;
-        if (k == audit_k) {                                     // a position that was NOT selected: its plain f32 score
+        if (k >= n_cand) {                                      // a position that was NOT selected: its plain f32 score
             err = fabsf(lb - ranked);
             if (err > e_pair * 1.001f + 1e-7f) *violated = 1;   // the model failed where nobody was looking: every position
             if (e_model > 0.f) atomicMax(&wg_ratio[1], __float_as_uint(err / e_model));
@@ -444,51 +486,69 @@ __device__ __forceinline__ void refine_body(const RefineParams& a, const int s_i
         }
         rerr[k] = err;
     };
-    if (n_chunks <= 256) {
-        // R candidates at a time: thread -> (candidate, chunk); then one thread per candidate adds its chunk sums in order
-        const int R = 256 / n_chunks;
-        for (int k0 = 0; k0 < n; k0 += R) {
-            const int slot = tid / n_chunks, ch = tid - slot * n_chunks;
-            const int k = k0 + slot;
-            double v = 0.0;
-            if (slot < R && k < n) {
-                const int m0 = ch * XM;
-                v = chunk_dot<T>(Tp + m0, Wp + key_pos(list[k]) + m0, min(XM, M - m0));
+    // threads <-> chunks; tasks in bundles of RB (one pass over the pattern for the bundle) and then one by one.  A thread of
+    // the first FFT_AUDIT * RB adds the chunk sums of its (task, position) in order.
+    const int nthr = REFINE_THREADS;
+    for (int t0 = 0; t0 < n_tasks;) {
+        const int nb = n_tasks - t0 >= RB ? RB : 1;
+        const T* wp[RB];
+        int64_t room[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int64_t p = (int64_t)key_pos(list[tent[t0 + (i < nb ? i : 0)]]);
+            wp[i] = Wp + p;
+            room[i] = a.r.dst_len - (sd.win_start + p);
+        }
+        double tot = 0.0;
+        for (int c0 = 0; c0 < n_chunks; c0 += nthr) {
+            const int ch = c0 + tid;
+            double v[RB][FFT_AUDIT];
+            if (ch < n_chunks) {
+                const int m0 = ch * XM, mc = min(XM, M - m0);
+                if (nb == RB) {
+                    const T* wc[RB];
+                    int64_t rc[RB];
+#pragma unroll
+                    for (int i = 0; i < RB; ++i) { wc[i] = wp[i] + m0; rc[i] = room[i] - m0; }
+                    chunk_bundle<T, RB>(Tp + m0, wc, mc, rc, v);
+                } else {
+                    const T* wc[1] = {wp[0] + m0};
+                    const int64_t rc[1] = {room[0] - m0};
+                    double v1[1][FFT_AUDIT];
+                    chunk_bundle<T, 1>(Tp + m0, wc, mc, rc, v1);
+#pragma unroll
+                    for (int q = 0; q < FFT_AUDIT; ++q) v[0][q] = v1[0][q];
+                }
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int q = 0; q < FFT_AUDIT; ++q)
+                        if (i < nb) part[(i * FFT_AUDIT + q) * nthr + tid] = v[i][q];
             }
-            part[tid] = v;
             __syncthreads();
-            if (tid < R && k0 + tid < n) {
-                double tot = 0.0;
-                for (int c = 0; c < n_chunks; ++c) tot += part[tid * n_chunks + c];
-                finish(k0 + tid, tot);
+            if (tid < FFT_AUDIT * nb) {
+                const int cn = min(nthr, n_chunks - c0);
+                for (int c = 0; c < cn; ++c) tot += part[tid * nthr + c];
             }
             __syncthreads();
         }
-    } else {
-        for (int k = 0; k < n; ++k) {
-            double tot = 0.0;
-            for (int c0 = 0; c0 < n_chunks; c0 += 256) {
-                const int ch = c0 + tid;
-                const int m0 = ch * XM;
-                part[tid] = ch < n_chunks ? chunk_dot<T>(Tp + m0, Wp + key_pos(list[k]) + m0, min(XM, M - m0)) : 0.0;
-                __syncthreads();
-                if (tid == 0)
-                    for (int c = 0; c < min(256, n_chunks - c0); ++c) tot += part[c];
-                __syncthreads();
-            }
-            if (tid == 0) finish(k, tot);
+        if (tid < FFT_AUDIT * nb) {
+            const int i = tid / FFT_AUDIT, q = tid % FFT_AUDIT;
+            if (q < tlen[t0 + i]) finish(tent[t0 + i] + q, tot);
         }
-        __syncthreads();
+        t0 += nb;
     }
+    __syncthreads();
 }
 
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(REFINE_THREADS)
 void refine_kernel(RefineParams a) {
-    __shared__ unsigned long long list[RCAP + 1], rkey[RCAP + 1];
-    __shared__ int lpair[RCAP + 1];
-    __shared__ float rerr[RCAP + 1];
-    __shared__ double part[256];
-    __shared__ int cnt, ovf, violated;
+    __shared__ unsigned long long list[RENT], rkey[RENT];
+    __shared__ int lpair[RENT];
+    __shared__ float rerr[RENT];
+    __shared__ short tent[RENT], tlen[RENT];
+    __shared__ double part[RB * FFT_AUDIT * REFINE_THREADS];
+    __shared__ int cnt, ovf, violated, n_all_s, n_tasks_s;
     __shared__ unsigned wg_ratio[2];             // this search's largest error / bound ratios (float bits): candidates, audit
     const int tid = threadIdx.x;
     const int s_idx = a.first_search + blockIdx.x;
@@ -500,9 +560,9 @@ void refine_kernel(RefineParams a) {
     const float U = a.gkeys[s_idx] == NO_KEY ? 4.0f : key_score(a.gkeys[s_idx]);
     const unsigned long long* __restrict__ rows = a.cand + (size_t)(sd.first_pair - a.sub_first_pair) * FFT_ROW;
     const float* __restrict__ plb = a.pair_lb + (sd.first_pair - a.sub_first_pair);
-    for (int i = tid; i < lay.n_pairs; i += 256) {
+    for (int i = tid; i < lay.n_pairs; i += REFINE_THREADS) {
         if (!(plb[i] <= U)) continue;                         // no position of this pair can be the extremum
-        for (int slot = 0; slot <= FFT_CAND; ++slot) {          // (slots behind FFT_CAND: the pair's error bound / audit position)
+        for (int slot = 0; slot <= FFT_CAND; ++slot) {          // (slots behind FFT_CAND: the pair's error bound / audit run)
             const unsigned long long key = rows[(size_t)i * FFT_ROW + slot];
             if (key != NO_KEY && key_score(key) <= U) {
                 if (slot == FFT_CAND) {
@@ -525,24 +585,40 @@ void refine_kernel(RefineParams a) {
         }
     }
     if (!ovf) {
-        // one position per search that is NOT a candidate, picked by a hash of the search index among the pairs' audit
-        // slots: evaluated exactly like the candidates and held to the same bound (the check of the error model where
-        // it was not already believed)
-        int n_all = n, audit_k = -1;
-        {
+        // AUDIT_PAIRS x FFT_AUDIT positions per search that are NOT candidates: the audit runs of pairs picked by a hash of the
+        // search index, spread over the window; evaluated exactly like the candidates and held to the same bound (the check of
+        // the error model where it was not already believed).  A run of FFT_AUDIT valid positions is one task; a run cut by the
+        // window's edge gives its valid positions one by one.
+        for (int t = tid; t < n; t += REFINE_THREADS) { tent[t] = (short)t; tlen[t] = 1; }
+        if (tid == 0) {
+            int n_all = n, n_tasks = n;
             const unsigned h = (unsigned)s_idx * 2654435761u;
-            const int pa = (int)((h >> 8) % (unsigned)lay.n_pairs);
-            const unsigned long long key = rows[(size_t)pa * FFT_ROW + FFT_CAND + 2];
-            if (key != NO_KEY) {
-                audit_k = n;
-                n_all = n + 1;
-                if (tid == 0) { list[n] = key; lpair[n] = pa; }
+            const int n_ap = lay.n_pairs < AUDIT_PAIRS ? lay.n_pairs : AUDIT_PAIRS;
+            const int step = lay.n_pairs / n_ap;
+            const int pa0 = (int)((h >> 8) % (unsigned)lay.n_pairs);
+            for (int j = 0; j < n_ap; ++j) {
+                const int pa = (pa0 + j * step) % lay.n_pairs;
+                unsigned long long key[FFT_AUDIT];
+                int valid = 0;
+                for (int q = 0; q < FFT_AUDIT; ++q) {
+                    key[q] = rows[(size_t)pa * FFT_ROW + FFT_CAND + 2 + q];
+                    valid += key[q] != NO_KEY ? 1 : 0;
+                }
+                if (valid == FFT_AUDIT) { tent[n_tasks] = (short)n_all; tlen[n_tasks] = FFT_AUDIT; ++n_tasks; }
+                for (int q = 0; q < FFT_AUDIT; ++q) {
+                    if (key[q] == NO_KEY) continue;
+                    if (valid != FFT_AUDIT) { tent[n_tasks] = (short)n_all; tlen[n_tasks] = 1; ++n_tasks; }
+                    list[n_all] = key[q]; lpair[n_all] = pa; ++n_all;
+                }
             }
+            n_all_s = n_all; n_tasks_s = n_tasks;
         }
         __syncthreads();
-        if (a.r.dtype == SUSHI_HIP_F32) refine_body<float>(a, s_idx, sd, list, lpair, rows, n_all, audit_k, part, rkey, rerr, &violated, wg_ratio);
-        else refine_body<uint8_t>(a, s_idx, sd, list, lpair, rows, n_all, audit_k, part, rkey, rerr, &violated, wg_ratio);
+        const int n_all = n_all_s, n_tasks = n_tasks_s;
+        if (a.r.dtype == SUSHI_HIP_F32) refine_body<float>(a, s_idx, sd, list, lpair, rows, n, n_all, tent, tlen, n_tasks, part, rkey, rerr, &violated, wg_ratio);
+        else refine_body<uint8_t>(a, s_idx, sd, list, lpair, rows, n, n_all, tent, tlen, n_tasks, part, rkey, rerr, &violated, wg_ratio);
         __syncthreads();
+        if (tid == 0 && n_all > n) atomicAdd(&a.counters->audited, (unsigned long long)(n_all - n));
     }
     if (tid == 0) {
         // the run's maxima: one global atomic per search only where it raises the value -- every workgroup hitting the same two
@@ -661,7 +737,7 @@ template <typename T>
 __global__ __launch_bounds__(PB_THREADS)
 void final_scan_kernel(const T* __restrict__ raw, int64_t n, const double* __restrict__ bs1,
                        const double* __restrict__ bs2, double* __restrict__ s1, double* __restrict__ s2,
-                       float* __restrict__ urel, float* __restrict__ srel) {
+                       float* __restrict__ urel, float* __restrict__ usrel) {
     // A thread scans PB_PER_THREAD consecutive samples, but global memory is touched a workgroup-wide row at a
     // time: samples come in and prefix values go out through a padded LDS tile (index + index / 16: the
     // 16-element runs of neighbouring threads start in different banks).
@@ -694,7 +770,7 @@ void final_scan_kernel(const T* __restrict__ raw, int64_t n, const double* __res
     const double o1 = bs1[blockIdx.x], o2 = bs2[blockIdx.x];             // block bases
     if (blockIdx.x == 0 && tid == 0) {
         s1[0] = 0.0; s2[0] = 0.0;
-        if (n % PB == 0) { urel[n] = 0.f; srel[n] = 0.f; }               // sample n opens a block of its own: base[n / PB] = total
+        if (n % PB == 0) { urel[n] = 0.f; usrel[2 * n] = 0.f; usrel[2 * n + 1] = 0.f; }   // sample n opens a block of its own: base[n / PB] = total
     }
     // s1[e + 1], s2[e + 1] (inclusive sums) and urel[e] (exclusive, relative to the block), one array at a time
     {
@@ -721,31 +797,32 @@ void final_scan_kernel(const T* __restrict__ raw, int64_t n, const double* __res
         if (blk + i < n) s2[blk + i + 1] = tile[pad(i)];
     }
     __syncthreads();
-    float* __restrict__ ftile = reinterpret_cast<float*>(tile);
+    // urel[e] (exclusive, relative to the block) and the same for the sum of the samples (TM_CCOEFF_NORMED's window means:
+    // s1[e] = base1[e / PB] + srel[e]); the pair goes out twice: urel alone (TM_SQDIFF_NORMED reads nothing else) and
+    // interleaved as usrel[e] = (urel[e], srel[e]), so that TM_CCOEFF_NORMED's scoring takes both with ONE 8-byte load per
+    // window end instead of two 4-byte ones
+    struct f2 { float u, s; };
+    f2* __restrict__ ftile = reinterpret_cast<f2*>(tile);
     {
-        double r = e2;
+        double r2 = e2, r1 = e1;
 #pragma unroll
-        for (int k = 0; k < PB_PER_THREAD; ++k) { ftile[pad(tid * PB_PER_THREAD + k)] = (float)r; r += v[k] * v[k]; }
+        for (int k = 0; k < PB_PER_THREAD; ++k) {
+            ftile[pad(tid * PB_PER_THREAD + k)] = f2{(float)r2, (float)r1};
+            r2 += v[k] * v[k];
+            r1 += v[k];
+        }
     }
     __syncthreads();
+    f2* __restrict__ us = reinterpret_cast<f2*>(usrel);
 #pragma unroll
     for (int k = 0; k < PB_PER_THREAD; ++k) {
         const int i = k * PB_THREADS + tid;
         // e == n inside this block (n % PB != 0): samples past the end are zeros, so the running sum there is the total
-        if (blk + i <= n) urel[blk + i] = ftile[pad(i)];
-    }
-    // the same for the sum of the samples (TM_CCOEFF_NORMED's window means): s1[e] = base1[e / PB] + srel[e]
-    __syncthreads();
-    {
-        double r = e1;
-#pragma unroll
-        for (int k = 0; k < PB_PER_THREAD; ++k) { ftile[pad(tid * PB_PER_THREAD + k)] = (float)r; r += v[k]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < PB_PER_THREAD; ++k) {
-        const int i = k * PB_THREADS + tid;
-        if (blk + i <= n) srel[blk + i] = ftile[pad(i)];
+        if (blk + i <= n) {
+            const f2 x = ftile[pad(i)];
+            urel[blk + i] = x.u;
+            us[blk + i] = x;
+        }
     }
 }
 
@@ -823,7 +900,7 @@ int launch_direct(const StreamRefs& r, const SearchDesc* searches_dev, int n_sea
 int launch_refine(const RefineParams& p, hipStream_t st) {
     hipLaunchKernelGGL(reset_sub_kernel, dim3(1), dim3(1), 0, st, p.sub_flagged, p.counters);
     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-    hipLaunchKernelGGL(refine_kernel, dim3(p.n_sub), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(refine_kernel, dim3(p.n_sub), dim3(REFINE_THREADS), 0, st, p);
     return launch_ok();
 }
 
@@ -852,7 +929,7 @@ StreamLayout stream_layout(int64_t n, int searchable) {
     l.s1 = o; o += align_up((size_t)(n + 1) * sizeof(double), 256);
     l.s2 = o; o += align_up((size_t)(n + 1) * sizeof(double), 256);
     l.urel = o; o += align_up((size_t)(n + 1) * sizeof(float), 256);
-    l.srel = o; o += align_up((size_t)(n + 1) * sizeof(float), 256);
+    l.srel = o; o += align_up((size_t)(n + 1) * 2 * sizeof(float), 256);     // usrel: (urel, srel) interleaved
     l.base_bytes = (size_t)(2 * (nb + 1) + 2) * sizeof(double);  // block bases of sum x^2, then of sum x, then the FFT path's stats
     l.base = o; o += align_up(l.base_bytes, 256);
     l.spec = o; o += searchable ? align_up(sushi_hip_stream_spectra_bytes(n), 256) : 0;
@@ -912,7 +989,7 @@ int sushi_hip_stream_create(const void* raw_dev, int dtype, int64_t n, int searc
     char* m = (char*)mem_dev;
     s->raw = raw_dev; s->dtype = dtype; s->n = n;
     s->xc = (float*)(m + l.xc); s->s1 = (double*)(m + l.s1); s->s2 = (double*)(m + l.s2);
-    s->urel = (float*)(m + l.urel); s->srel = (float*)(m + l.srel); s->base = (double*)(m + l.base); s->base_bytes = l.base_bytes;
+    s->urel = (float*)(m + l.urel); s->usrel = (float*)(m + l.srel); s->base = (double*)(m + l.base); s->base_bytes = l.base_bytes;
     s->spec = nullptr; s->spec_bytes = 0; s->blocks = nb; s->stats = s->base + 2 * (nb + 1);
     hipStream_t st = (hipStream_t)hip_stream;
     double* bs2 = s->base;                       // block bases of sum x^2 (what the FFT path's scoring reads)
@@ -931,10 +1008,10 @@ int sushi_hip_stream_create(const void* raw_dev, int dtype, int64_t n, int searc
     if (rc == SUSHI_HIP_OK) {
         if (dtype == SUSHI_HIP_F32)
             hipLaunchKernelGGL(final_scan_kernel<float>, dim3(nb), dim3(PB_THREADS), 0, st, (const float*)raw_dev, n,
-                               (const double*)bs1, (const double*)bs2, s->s1, s->s2, s->urel, s->srel);
+                               (const double*)bs1, (const double*)bs2, s->s1, s->s2, s->urel, s->usrel);
         else
             hipLaunchKernelGGL(final_scan_kernel<uint8_t>, dim3(nb), dim3(PB_THREADS), 0, st, (const uint8_t*)raw_dev, n,
-                               (const double*)bs1, (const double*)bs2, s->s1, s->s2, s->urel, s->srel);
+                               (const double*)bs1, (const double*)bs2, s->s1, s->s2, s->urel, s->usrel);
         rc = launch_ok();
     }
     if (rc == SUSHI_HIP_OK) {
@@ -957,7 +1034,7 @@ int sushi_hip_stream_view(const SushiHipStream* s, int which, const void** ptr_d
         case SUSHI_HIP_VIEW_UREL: *ptr_dev = s->urel; *bytes = (size_t)(s->n + 1) * sizeof(float); break;
         case SUSHI_HIP_VIEW_BASE: *ptr_dev = s->base; *bytes = (size_t)(s->blocks + 1) * sizeof(double); break;
         case SUSHI_HIP_VIEW_SPECTRA: *ptr_dev = s->spec; *bytes = s->spec_bytes; break;
-        case SUSHI_HIP_VIEW_SREL: *ptr_dev = s->srel; *bytes = (size_t)(s->n + 1) * sizeof(float); break;
+        case SUSHI_HIP_VIEW_USREL: *ptr_dev = s->usrel; *bytes = (size_t)(s->n + 1) * 2 * sizeof(float); break;
         case SUSHI_HIP_VIEW_BASE1: *ptr_dev = s->base + (s->blocks + 1); *bytes = (size_t)(s->blocks + 1) * sizeof(double); break;
         default: return SUSHI_HIP_EINVAL;
     }

@@ -17,7 +17,7 @@ struct SushiHipStream {
     double* s1;               // [n + 1]  prefix sums of the samples
     double* s2;               // [n + 1]  prefix sums of their squares
     float* urel;              // [n + 1]  s2 relative to the block base
-    float* srel;              // [n + 1]  s1 relative to the block base (TM_CCOEFF_NORMED on the FFT path)
+    float* usrel;             // [n + 1][2]  (urel[e], s1 relative to the block base): TM_CCOEFF_NORMED on the FFT path, one 8-byte load per window end
     double* base;             // [nb + 1] block bases of s2, then [nb + 1] block bases of s1, then `stats`
     double* stats;            // [2] FFT path: largest centred energy of seven consecutive blocks; the centring constant
     size_t base_bytes;
@@ -65,6 +65,7 @@ struct RunCounters {
     unsigned long long tiles_dense, tiles_sparse, candidates;    // totals of the run
     uint32_t max_ratio_bits;  // float bits of SushiHipBatchDiag.max_bound_ratio
     uint32_t max_ratio_audit_bits;  // float bits of SushiHipBatchDiag.max_bound_ratio_noncandidate
+    unsigned long long audited;     // non-candidate positions evaluated exactly (SushiHipBatchDiag.audited)
 };
 
 int direct_variant_count();

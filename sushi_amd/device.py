@@ -119,7 +119,7 @@ class DeviceStream(object):
     s1 = property(lambda self: self._view(_native.VIEW_S1, torch.float64))
     s2 = property(lambda self: self._view(_native.VIEW_S2, torch.float64))
     urel = property(lambda self: self._view(_native.VIEW_UREL, torch.float32))
-    srel = property(lambda self: self._view(_native.VIEW_SREL, torch.float32))
+    usrel = property(lambda self: self._view(_native.VIEW_USREL, torch.float32))      # [n + 1][2] flattened: (urel, srel) pairs
     base1 = property(lambda self: self._view(_native.VIEW_BASE1, torch.float64))
     base = property(lambda self: self._view(_native.VIEW_BASE, torch.float64))
 
