@@ -152,7 +152,8 @@ def oracle_leg(dst_row, src_row, offs, lens, wst, npos, method, forced, timed, m
     cores, quota = usable_cores()
     used = max(1, min(cores if workers is None else workers, n))
     forced = [int(k) for k in forced]
-    rest = [k for k in _spread(n) if k not in set(forced)]
+    _forced_set = set(forced)
+    rest = [k for k in _spread(n) if k not in _forced_set]
     must = forced + rest[:max(0, min_sample - len(forced))]         # the parity sample: always
     more = rest[max(0, min_sample - len(forced)):] if timed else []
     if have_cv2:                        # the real call on an evenly spread part of the sample (bounded: it is slow too)
@@ -308,9 +309,19 @@ def main():
     # SUSHI_BENCH_CACHE=<dir>: keep the normalised streams of a workload between runs on one box (the profiling
     # scripts run this file several times; generating 2 x 86 M samples takes longer than the measurement)
     cache = os.environ.get("SUSHI_BENCH_CACHE")
+    if cache is None and world > 1:
+        # N ranks share the host's cores (the GPU boxes grant a 16-core quota): rank 0 generates the two streams ONCE and the
+        # others read its file instead of each repeating the work (keyed by the rendezvous port: one directory per launch)
+        cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "sushi_bench_streams_%s" % os.environ.get("MASTER_PORT", "0"))
     tag = "c%d_%g_%d_%s_%g_%g" % (args.config, cfg["minutes"], rate, args.sample_type, args.offset, args.hard_frac)
     cpath = os.path.join(cache, tag + ".npz") if cache else None
     hard_spans = []
+    if cpath and rank != 0 and world > 1:
+        t_wait = time.perf_counter()
+        while not os.path.exists(cpath):                       # written atomically (os.replace) by rank 0
+            if time.perf_counter() - t_wait > 1800:
+                raise SystemExit("rank %d: no stream file from rank 0 after 30 min (%s)" % (rank, cpath))
+            time.sleep(0.2)
     if cpath and os.path.exists(cpath):
         z = np.load(cpath, allow_pickle=True)
         dst = WavStream.from_prepared(z["dst"], rate, int(z["sample_count"]), int(z["padding_size"]))
@@ -394,8 +405,11 @@ def main():
                                workspace_bytes=(160 << 30) if args.ws_mb is None else args.ws_mb << 20,
                                method=args.method)
 
+    # blocks of equal WORK per rank: a step is as long as its slowest rank
+    from sushi_amd.device import search_work
+    work = search_work(wst, npos, lens, args.path)
     t_b = time.perf_counter()
-    sharded = ShardedSearch(n_total, make_batch, device=None if dry else dev)
+    sharded = ShardedSearch(n_total, make_batch, device=None if dry else dev, weights=work if world > 1 else None)
     batch = sharded.batch
     if not dry:
         torch.cuda.synchronize(dev)
@@ -624,6 +638,9 @@ def main():
                                       int(np.median(npos))),
                        "baseline_config_index": args.config, "global_events": n_total,
                        "events_per_gpu": [shard[1] - shard[0] for shard in sharded.all_bounds()],
+                       # sum of the searches' work (block pairs x segments) per rank over the mean: the step is its slowest rank
+                       "work_per_gpu_over_mean": [round(float(work[a:b].sum() / (work.sum() / world)), 4)
+                                                  for a, b in sharded.all_bounds()],
                        "window_s": cfg["window"], "stream_minutes": cfg["minutes"], "sample_rate": rate,
                        "sample_type": args.sample_type, "hard_events": int(hard_mask.sum()),
                        "method": METHOD_TEXT[args.method],
@@ -637,6 +654,10 @@ def main():
             "parity": parity,
             # paid once per job, before the first step; outside `value` (inputs resident in HBM when the timed region starts)
             "setup_ms": setup_ms,
+            # `value` is a RESIDENT-STATE rate (streams, spectra, plan and workspace in HBM, the same job every step).  What a
+            # one-shot job -- sushi.py:663-672: two WavStream loads, then one calculate_shifts pass -- gets from this process:
+            # events / (set-up + one step)
+            "one_shot_events_per_s": None if not setup_ms else n_total / ((sum(setup_ms.values()) + elapsed / args.steps * 1e3) * 1e-3),
         }
         if dry:
             out["dry_run"] = "control flow only (--dry-backend %s): `value` is not a measurement" % args.dry_backend

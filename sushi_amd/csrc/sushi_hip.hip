@@ -436,8 +436,7 @@ __global__ void unpack_keys_kernel(const unsigned long long* __restrict__ keys, 
 constexpr int RCAP = 128;
 constexpr int RAUD = AUDIT_PAIRS * FFT_AUDIT;     // audited non-candidate positions per search
 constexpr int RENT = RCAP + RAUD;                // list entries: candidates, then audit positions
-constexpr int RB = 1 + AUDIT_PAIRS;              // tasks per bundle: the usual search is one candidate and AUDIT_PAIRS audit runs
-constexpr int REFINE_THREADS = 128;              // one thread per 512-sample chunk of the pattern: 5.4 s at 12 kHz in one pass
+constexpr int REFINE_THREADS = 384;              // thread <-> (task, chunk): the usual search (one candidate + AUDIT_PAIRS runs, a 3 s pattern = 71 chunks) in one round
 
 // Entries [0, n_cand) of the list are candidates; entries [n_cand, n_all) are audit positions: NOT selected, with their plain
 // f32 scores, evaluated like the others and only checked against the bound (the two-sided check of the error model).
@@ -486,57 +485,42 @@ __device__ __forceinline__ void refine_body(const RefineParams& a, const int s_i
         }
         rerr[k] = err;
     };
-    // threads <-> chunks; tasks in bundles of RB (one pass over the pattern for the bundle) and then one by one.  A thread of
-    // the first FFT_AUDIT * RB adds the chunk sums of its (task, position) in order.
-    const int nthr = REFINE_THREADS;
-    for (int t0 = 0; t0 < n_tasks;) {
-        const int nb = n_tasks - t0 >= RB ? RB : 1;
-        const T* wp[RB];
-        int64_t room[RB];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int64_t p = (int64_t)key_pos(list[tent[t0 + (i < nb ? i : 0)]]);
-            wp[i] = Wp + p;
-            room[i] = a.r.dst_len - (sd.win_start + p);
-        }
+    // thread <-> (task, chunk): R tasks at a time (all of the usual search's five in one round); then one thread per
+    // (task, position) adds its chunk sums in order.  Patterns of more chunks than threads: one task at a time, chunk groups.
+    constexpr int nthr = REFINE_THREADS;
+    const bool small = n_chunks <= nthr;
+    const int R = small ? nthr / n_chunks : 1;
+    const int cpr = small ? n_chunks : nthr;                     // chunks per round and task
+    for (int t0 = 0; t0 < n_tasks; t0 += R) {
+        const int slot = small ? tid / n_chunks : 0;
+        const int t = t0 + slot;
+        const bool have = slot < R && t < n_tasks;
+        const int64_t p = have ? (int64_t)key_pos(list[tent[t]]) : 0;
         double tot = 0.0;
-        for (int c0 = 0; c0 < n_chunks; c0 += nthr) {
-            const int ch = c0 + tid;
-            double v[RB][FFT_AUDIT];
-            if (ch < n_chunks) {
-                const int m0 = ch * XM, mc = min(XM, M - m0);
-                if (nb == RB) {
-                    const T* wc[RB];
-                    int64_t rc[RB];
-#pragma unroll
-                    for (int i = 0; i < RB; ++i) { wc[i] = wp[i] + m0; rc[i] = room[i] - m0; }
-                    chunk_bundle<T, RB>(Tp + m0, wc, mc, rc, v);
-                } else {
-                    const T* wc[1] = {wp[0] + m0};
-                    const int64_t rc[1] = {room[0] - m0};
-                    double v1[1][FFT_AUDIT];
-                    chunk_bundle<T, 1>(Tp + m0, wc, mc, rc, v1);
-#pragma unroll
-                    for (int q = 0; q < FFT_AUDIT; ++q) v[0][q] = v1[0][q];
-                }
-#pragma unroll
-                for (int i = 0; i < RB; ++i)
-#pragma unroll
-                    for (int q = 0; q < FFT_AUDIT; ++q)
-                        if (i < nb) part[(i * FFT_AUDIT + q) * nthr + tid] = v[i][q];
+        for (int c0 = 0; c0 < n_chunks; c0 += cpr) {
+            const int cl = small ? tid - slot * n_chunks : tid;   // chunk inside the round
+            const int ch = c0 + cl;
+            double v[1][FFT_AUDIT] = {{0.0, 0.0, 0.0, 0.0}};
+            if (have && ch < n_chunks) {
+                const int m0 = ch * XM;
+                const T* wc[1] = {Wp + p + m0};
+                const int64_t rc[1] = {a.r.dst_len - (sd.win_start + p + m0)};
+                chunk_bundle<T, 1>(Tp + m0, wc, min(XM, M - m0), rc, v);
             }
+#pragma unroll
+            for (int q = 0; q < FFT_AUDIT; ++q) part[FFT_AUDIT * tid + q] = v[0][q];
             __syncthreads();
-            if (tid < FFT_AUDIT * nb) {
-                const int cn = min(nthr, n_chunks - c0);
-                for (int c = 0; c < cn; ++c) tot += part[tid * nthr + c];
+            if (tid < FFT_AUDIT * R) {
+                const int fs = tid / FFT_AUDIT, q = tid % FFT_AUDIT;
+                const int cn = min(cpr, n_chunks - c0);
+                for (int c = 0; c < cn; ++c) tot += part[FFT_AUDIT * (fs * cpr + c) + q];
             }
             __syncthreads();
         }
-        if (tid < FFT_AUDIT * nb) {
-            const int i = tid / FFT_AUDIT, q = tid % FFT_AUDIT;
-            if (q < tlen[t0 + i]) finish(tent[t0 + i] + q, tot);
+        if (tid < FFT_AUDIT * R) {
+            const int fs = tid / FFT_AUDIT, q = tid % FFT_AUDIT;
+            if (t0 + fs < n_tasks && q < tlen[t0 + fs]) finish(tent[t0 + fs] + q, tot);
         }
-        t0 += nb;
     }
     __syncthreads();
 }
@@ -547,7 +531,7 @@ void refine_kernel(RefineParams a) {
     __shared__ int lpair[RENT];
     __shared__ float rerr[RENT];
     __shared__ short tent[RENT], tlen[RENT];
-    __shared__ double part[RB * FFT_AUDIT * REFINE_THREADS];
+    __shared__ double part[FFT_AUDIT * REFINE_THREADS];
     __shared__ int cnt, ovf, violated, n_all_s, n_tasks_s;
     __shared__ unsigned wg_ratio[2];             // this search's largest error / bound ratios (float bits): candidates, audit
     const int tid = threadIdx.x;

@@ -4,6 +4,8 @@ The path shards by event: every search reads only the two (replicated) streams, 
 nothing on the data path.  Each rank takes a contiguous block of the (time-sorted) searches --
 neighbouring events overlap in the destination stream, which keeps a rank's working set local --
 and the only collective is one all-gather of the per-event (index, score) pairs: 8 bytes per event.
+Blocks are cut by WORK, not by count ("balance by sum P*M"): a search costs its block pairs x pattern
+segments on the FFT path, and a step is as long as its slowest rank.
 """
 import numpy as np
 import torch
@@ -19,6 +21,29 @@ def shard_bounds(n_items, rank, world_size):
 
 def max_shard(n_items, world_size):
     return (n_items + world_size - 1) // world_size
+
+
+def weighted_bounds(weights, world_size):
+    """Contiguous blocks [(lo, hi)] * world_size over len(weights) items with nearly equal sums of `weights`
+    (all > 0): boundary r is where the running sum crosses r / world_size of the total -- every rank computes the same
+    cut from the same descriptors.  No block is empty while there are at least world_size items."""
+    w = np.asarray(weights, dtype=np.float64).reshape(-1)
+    n = w.shape[0]
+    if n == 0:
+        return [(0, 0)] * world_size
+    c = np.concatenate(([0.0], np.cumsum(w)))
+    cuts = [0]
+    for r in range(1, world_size):
+        target = c[-1] * r / world_size
+        k = int(np.searchsorted(c, target))                    # first k with c[k] >= target
+        if k > 0 and abs(c[k - 1] - target) <= abs(c[k] - target):
+            k -= 1                                              # the nearer of the two neighbouring cuts
+        lo_allowed = cuts[-1] + 1 if n >= world_size else cuts[-1]
+        k = max(k, lo_allowed)
+        k = min(k, n - (world_size - r) if n >= world_size else n)
+        cuts.append(k)
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
 
 
 def pack_results(idx, score, pad_to):
@@ -54,24 +79,31 @@ class ShardedSearch(object):
     searches [lo, hi) (a `SearchBatch` on the GPU; the CPU tests pass a stand-in).  `device`: where a rank
     WITHOUT searches (more ranks than searches) allocates its empty contribution -- RCCL gathers device
     tensors only, so it must be this rank's GPU under the nccl backend (None: CPU, for gloo).
+    `weights` (one positive number per search, the same on every rank): blocks of equal work instead of equal count.
 
-    The gather's buffers are allocated once: a step costs two small copies into the packed block, the one collective,
-    and -- when every rank holds the same number of searches (3000 events on 8 GPUs) -- no kernel at all on the way out
-    (the results are strided views of the gathered buffer); at 375 events per rank a step is 3.5 ms of kernels, and a
-    dozen tiny launches around the collective would be a few per cent of it."""
+    The gather's buffers are allocated once: a step costs two small copies into the packed block, the one collective and
+    one (equal blocks) or two (unequal blocks) small kernels on the way out; at 375 events per rank a step is 3.5 ms of
+    kernels, and a dozen tiny launches around the collective would be a few per cent of it.
 
-    def __init__(self, n_total, make_batch, group=None, device=None):
+    CONTRACT of gather() / run(): the two returned tensors are CONTIGUOUS rows of one persistent buffer of this object --
+    valid until the next gather(), which overwrites them in place.  Keep results across steps with .clone()."""
+
+    def __init__(self, n_total, make_batch, group=None, device=None, weights=None):
         self.n_total = n_total
         self.group = group
         self.device = device
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.lo, self.hi = shard_bounds(n_total, self.rank, self.world)
+        if weights is not None and len(weights) != n_total:
+            raise ValueError("one weight per search")
+        self._bounds = (weighted_bounds(weights, self.world) if weights is not None else
+                        [shard_bounds(n_total, r, self.world) for r in range(self.world)])
+        self.lo, self.hi = self._bounds[self.rank]
         self.batch = make_batch(self.lo, self.hi) if self.hi > self.lo else None
-        self._packed = self._full = None
+        self._packed = self._full = self._out = self._rows = self._sel = None
 
     def all_bounds(self):
-        return [shard_bounds(self.n_total, r, self.world) for r in range(self.world)]
+        return list(self._bounds)
 
     def run_local(self):
         """This rank's block: (idx int32[hi - lo], score float32[hi - lo]) on this rank's device."""
@@ -84,23 +116,26 @@ class ShardedSearch(object):
         """The one collective of the path: everyone's (idx, score) in global search order."""
         if self.world == 1:
             return idx, score
-        pad = max_shard(self.n_total, self.world)
+        pad = max(hi - lo for lo, hi in self._bounds)
         if self._packed is None or self._packed.device != idx.device:
-            self._packed = torch.full((pad, 2), -1, dtype=torch.int32, device=idx.device)
-            self._full = torch.empty((self.world * pad, 2), dtype=torch.int32, device=idx.device)
+            dev = idx.device
+            self._packed = torch.full((pad, 2), -1, dtype=torch.int32, device=dev)
+            self._full = torch.empty((self.world * pad, 2), dtype=torch.int32, device=dev)
+            self._out = torch.empty((2, self.n_total), dtype=torch.int32, device=dev)
+            if self.n_total != self.world * pad:              # unequal blocks: the rows of the gathered buffer that exist
+                sel = np.concatenate([np.arange(hi - lo, dtype=np.int64) + r * pad for r, (lo, hi) in enumerate(self._bounds)])
+                self._sel = torch.from_numpy(sel).to(dev)
+                self._rows = torch.empty((self.n_total, 2), dtype=torch.int32, device=dev)
         n = idx.shape[0]
         self._packed[:n, 0].copy_(idx)
         self._packed[:n, 1].copy_(score.view(torch.int32))
         dist.all_gather_into_tensor(self._full, self._packed, group=self.group)
-        if self.n_total == self.world * pad:                  # equal blocks: the gathered buffer IS the result, in order
-            return self._full[:, 0], self._full[:, 1].view(torch.float32)
-        full = self._full.view(self.world, pad, 2)
-        pieces_i, pieces_s = [], []
-        for r in range(self.world):
-            lo, hi = shard_bounds(self.n_total, r, self.world)
-            pieces_i.append(full[r, :hi - lo, 0])
-            pieces_s.append(full[r, :hi - lo, 1])
-        return torch.cat(pieces_i), torch.cat(pieces_s).view(torch.float32)
+        rows = self._full
+        if self._sel is not None:
+            torch.index_select(self._full, 0, self._sel, out=self._rows)
+            rows = self._rows
+        self._out.copy_(rows.t())                             # de-interleave: two contiguous rows
+        return self._out[0], self._out[1].view(torch.float32)
 
     def run(self):
         return self.gather(*self.run_local())

@@ -38,6 +38,8 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert d["parity"]["max_shift_err_samples_vs_planted"] <= 1.0
     assert d["parity"]["max_idx_err_vs_oracle_sample"] == 0 and d["parity"]["oracle_sample_searches"] >= 8
     assert d["config"]["global_events"] == 24 and d["config"]["events_per_gpu"] == [24]
+    # `value` is a resident-state rate; the line also says what a one-shot job gets (set-up + one step)
+    assert 0 < d["one_shot_events_per_s"] < d["value"] and sum(d["setup_ms"].values()) > 0
     assert "custom" in d["config"]["workload"]
 
 

@@ -34,8 +34,10 @@ def test_two_rank_dry_run_prints_one_line_with_per_rank_bookkeeping():
     assert len(lines) == 1                                        # rank 0 only
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and "dry_run" in d
-    assert d["config"]["global_events"] == 25 and d["config"]["events_per_gpu"] == [13, 12]
-    assert [r["rank"] for r in d["per_rank"]] == [0, 1] and [r["events"] for r in d["per_rank"]] == [13, 12]
+    per = d["config"]["events_per_gpu"]
+    assert d["config"]["global_events"] == 25 and sum(per) == 25 and min(per) >= 10         # blocks of equal WORK, not count
+    assert max(d["config"]["work_per_gpu_over_mean"]) <= 1.1
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1] and [r["events"] for r in d["per_rank"]] == per
     assert d["parity"]["max_shift_err_samples_vs_planted"] <= 1.0      # the gathered results are in global order
     assert d["value"] > 0 and d["cpu_baseline"] is None
 
@@ -46,3 +48,17 @@ def test_a_failed_verification_ends_every_rank():
     out = _run(2, ["--offset", "7.25", "--dry-plant-error", "5"])
     assert out.returncode != 0
     assert "planted offset not recovered" in (out.stderr + out.stdout)
+
+
+def test_eight_rank_dry_run():
+    """The launch an 8-GPU node gets (one process per GPU), with the stand-in batch: rank 0 generates the streams once, the
+    others read its file; eight blocks of equal work; one line out."""
+    out = _run(8, ["--events", "64"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and sum(d["config"]["events_per_gpu"]) == 64 and min(d["config"]["events_per_gpu"]) >= 5
+    assert max(d["config"]["work_per_gpu_over_mean"]) <= 1.15      # 8 events per rank: one event is 12 % of a block
+    assert [r["rank"] for r in d["per_rank"]] == list(range(8))
+    assert d["parity"]["max_shift_err_samples_vs_planted"] <= 1.0
