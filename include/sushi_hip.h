@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SUSHI_HIP_ABI_VERSION 9   /* 9: SushiHipBatchDiag.audited (16 audited non-candidate positions per search) */
+#define SUSHI_HIP_ABI_VERSION 9   /* 9: SushiHipBatchDiag.audited / .pairs_transformed, SUSHI_HIP_STAGE_BOUND, (urel, srel) interleaved */
 
 #if defined(__GNUC__)
 #define SUSHI_HIP_API __attribute__((visibility("default")))
@@ -149,6 +149,8 @@ typedef struct SushiHipBatchDiag {
                                  all_positions too.  The bound is a statistical model (8 standard deviations of the packed-half
                                  roundings), not a worst-case proof: this field is what watches it. */
     int64_t audited;          /* audited non-candidate positions of the run */
+    int64_t pairs_transformed; /* FFT path, TM_SQDIFF_NORMED: block pairs whose inverse transform was run and scored; the other
+                                 info.fft_pairs - this were excluded by a lower bound of their scores (bound_kernel) */
 } SushiHipBatchDiag;
 
 typedef struct SushiHipBatch SushiHipBatch;
@@ -219,12 +221,13 @@ SUSHI_HIP_API int sushi_hip_load_normalise(float* data_dev, int64_t n, float lo,
  * figures).  Between _begin and _end every sushi_hip_batch_run records its stage boundaries; _end waits for them and
  * writes, per run, the milliseconds spent in each stage (summed over the run's sub-batches) into
  * stage_ms[run][SUSHI_HIP_NSTAGES].  Not thread safe. */
-#define SUSHI_HIP_NSTAGES 5
+#define SUSHI_HIP_NSTAGES 6
 #define SUSHI_HIP_STAGE_TSPEC 0    /* pattern-segment DFTs                                          */
 #define SUSHI_HIP_STAGE_MAC 1      /* frequency-domain multiply-accumulate                          */
 #define SUSHI_HIP_STAGE_IFFT 2     /* inverse DFTs + scoring epilogue                               */
 #define SUSHI_HIP_STAGE_REFINE 3   /* exact float64 evaluation of the listed candidates             */
 #define SUSHI_HIP_STAGE_FINISH 4   /* candidate collection + exact tiles of flagged searches, unpack */
+#define SUSHI_HIP_STAGE_BOUND 5    /* lower bounds of the block pairs' scores (three of the inverse transform's four passes)  */
 SUSHI_HIP_API int sushi_hip_profile_begin(void);
 SUSHI_HIP_API int sushi_hip_profile_end(float* stage_ms, int max_calls, int* n_calls);
 

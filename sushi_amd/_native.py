@@ -22,10 +22,10 @@ METHODS = {"sqdiff_normed": METHOD_SQDIFF_NORMED, "ccoeff_normed": METHOD_CCOEFF
 VIEW_XC, VIEW_S1, VIEW_S2, VIEW_UREL, VIEW_BASE, VIEW_SPECTRA, VIEW_USREL, VIEW_BASE1 = range(8)
 
 ABI_VERSION = 9
-NSTAGES = 5
-STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish")
+NSTAGES = 6
+STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish", "bound")
 STAGE_KERNELS = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "ifft_kernel", "refine": "refine_kernel",
-                 "finish": "collect_kernel+exact_tiles_kernel+unpack_keys_kernel"}
+                 "finish": "collect_kernel+exact_tiles_kernel+unpack_keys_kernel", "bound": "bound_kernel"}
 
 # struct SushiHipRequest, 24 bytes
 REQUEST_DTYPE = np.dtype([("tmpl_off", "<i8"), ("win_start", "<i8"), ("tmpl_len", "<i4"), ("n_pos", "<i4")], align=True)
@@ -42,7 +42,8 @@ class BatchInfo(ctypes.Structure):
 class BatchDiag(ctypes.Structure):
     _fields_ = [("flagged", ctypes.c_int32), ("all_positions", ctypes.c_int32), ("tiles_dense", ctypes.c_int64),
                 ("tiles_sparse", ctypes.c_int64), ("candidates", ctypes.c_int64), ("max_bound_ratio", ctypes.c_float),
-                ("max_bound_ratio_noncandidate", ctypes.c_float), ("audited", ctypes.c_int64)]
+                ("max_bound_ratio_noncandidate", ctypes.c_float), ("audited", ctypes.c_int64),
+                ("pairs_transformed", ctypes.c_int64)]
 
 
 _lib = None

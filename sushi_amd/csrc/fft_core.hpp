@@ -477,8 +477,12 @@ __device__ __forceinline__ MfmaB load_mfma_b(int tid, const uint4v* __restrict__
     b.il = __builtin_bit_cast(half8, table[3 * 64 + lane]);
     return b;
 }
+// Passes 1 - 3 (everything that stays inside a wave): v[4 e3 + e2lo] of lane (e2hi = lane >> 4, e1 = lane & 15) of wave n1 ends
+// as A_n1[k2] = sum_n2 x[n1 + 16 n2] w1024^(n2 k2), k2 = e1 + 64 e2hi + 16 e2lo + 256 e3 -- the 1024-point transform of the
+// wave's decimated share of the input.  Every output of the whole transform is a sum of sixteen of these, one per wave, times
+// unit factors:  |X[k2 + 1024 k1]| <= sum_n1 |A_n1[k2]|  (what bound_kernel uses to leave a block pair untransformed).
 template <int DIR>
-__device__ __forceinline__ void fft_wave_mfma(const uint4v (&yl)[4], cpx* v, int tid, float* lds, const WTwiddles tw, const MfmaB& b) {
+__device__ __forceinline__ void fft_wave_mfma_front(const uint4v (&yl)[4], cpx* v, int tid, const WTwiddles tw, const MfmaB& b) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         // (re, im) x 4 bins -> re x 8 in the lanes below 32, im x 8 in the lanes above (the other four bins are the partner lane's)
@@ -511,6 +515,10 @@ __device__ __forceinline__ void fft_wave_mfma(const uint4v (&yl)[4], cpx* v, int
     for (int r = 0; r < 16; ++r)
         if ((r & 4) == 0) { swap16(v[r].x, v[r + 4].x); swap16(v[r].y, v[r + 4].y); }
     w_pass3<DIR>(v, tw.q3);                                      // pass 3
+}
+// The workgroup exchange and pass 4.
+template <int DIR>
+__device__ __forceinline__ void fft_wave_mfma_back(cpx* v, int tid, float* lds, const WTwiddles tw) {
     w_wg_store<0>(v, tid, lds);                                  // (no wave used the buffer before: no barrier in front)
     __syncthreads();
     w_wg_load<0>(v, tid, lds);
@@ -519,6 +527,11 @@ __device__ __forceinline__ void fft_wave_mfma(const uint4v (&yl)[4], cpx* v, int
     __syncthreads();
     w_wg_load<1>(v, tid, lds);
     pass_compute<16, WNT, DIR>(v, tw.p4);                        // pass 4
+}
+template <int DIR>
+__device__ __forceinline__ void fft_wave_mfma(const uint4v (&yl)[4], cpx* v, int tid, float* lds, const WTwiddles tw, const MfmaB& b) {
+    fft_wave_mfma_front<DIR>(yl, v, tid, tw, b);
+    fft_wave_mfma_back<DIR>(v, tid, lds, tw);
 }
 #endif  // __HIPCC__
 

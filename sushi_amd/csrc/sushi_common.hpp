@@ -23,16 +23,17 @@ constexpr int FFT_VB = FFT_N / FFT_SEG - 1;        // valid blocks per half of a
 constexpr int FFT_H = FFT_VB * FFT_SEG;            // result positions per half
 constexpr int FFT_STEP = 2 * FFT_VB;               // blocks between consecutive pairs
 constexpr int FFT_CAND = 8;                        // candidate slots per block pair (+ overflow marker + error bound + audit positions)
-constexpr int FFT_AUDIT = 4;                       // audit positions a pair leaves: a run of consecutive positions (one exact evaluation's worth of loads)
-constexpr int FFT_ROW = 16;                        // 64-bit entries per pair in the candidate array: a 128-byte line
-static_assert(FFT_CAND + 2 + FFT_AUDIT <= FFT_ROW, "candidates, overflow marker, error bound, audit run");
-constexpr int AUDIT_PAIRS = 4;                     // pairs per search whose audit run refine_kernel evaluates exactly: 16 non-candidate positions
+constexpr int FFT_AUDIT = 4;                       // positions of an audit run: consecutive (one exact evaluation's worth of loads)
+constexpr int AUDIT_RUNS = 4;                      // audit runs a transformed pair leaves, and audit runs refine_kernel evaluates per search
+constexpr int FFT_ROW = 32;                        // 64-bit entries per pair in the candidate array: two 128-byte lines
+static_assert(FFT_CAND + 2 + AUDIT_RUNS * FFT_AUDIT <= FFT_ROW, "candidates, overflow marker, error bound, audit runs");
 constexpr int TILE = 1024;                         // positions per exact-evaluation tile (aligned to the absolute grid)
 constexpr int TILES_PER_PAIR = 2 * FFT_H / TILE;
 // error model of the f32 FFT stage: |corr_f32 - corr| <= FFT_KE * 2^-24 * |T| * |Z|, Z = the samples that enter the
 // pair's transforms (n_seg + 2 * FFT_VB blocks).  Calibrated: the largest ratio measured over the parity and property
 // tests is recorded by refine_kernel (diagnostics) and stays below FFT_KE / 3; a candidate whose exact score
 // violates its bound sends the whole search to exact evaluation.
+constexpr int COARSE_G = 256;                      // granularity of the coarse prefix table (SushiHipStream.coarse)
 constexpr float FFT_KE = 32.0f;
 constexpr unsigned long long NO_KEY = ~0ull;
 

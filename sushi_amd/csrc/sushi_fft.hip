@@ -535,7 +535,8 @@ struct IfftArgs {
     float* pair_lb;                   // [pairs of the sub-batch] smallest lower bound (score - e) of the pair: what refine_kernel scans
     unsigned long long* gkeys;        // [all searches] running minimum of (f32 score + error bound)
     const int* pairmap;               // [pairs of the sub-batch] -> search index inside the sub-batch
-    const int* order;                 // [pairs of the sub-batch] workgroup -> pair (L2-friendly schedule) or NULL
+    const int* order;                 // [pairs of the sub-batch] workgroup -> pair (L2-friendly schedule; or a list of pairs), or NULL
+    const int* count;                 // NULL, or how many entries of `order` exist: workgroups beyond leave at once
     const TemplConsts* tconst;        // [searches of the sub-batch]
     const float* urel;                // dst stream: prefix of the uncentred squares relative to its block's base
     const double* ubase;              // dst stream: those block bases [nb + 1]
@@ -930,6 +931,7 @@ void ifft_kernel(IfftArgs a) {
     __shared__ float red_q[FT / 64];            // per wave: energy of its share of the Y row
     __shared__ int ccnt, unc_any;
     const int tid = threadIdx.x;
+    if (a.count && (int)blockIdx.x >= *a.count) return;               // a list shorter than the grid (the pairs bound_kernel left)
     // which pair: by default the workgroup index; with a schedule the pairs that read the same region of the
     // destination stream run back to back on one XCD, so that the prefix-sum lines they share are fetched into that
     // XCD's L2 once instead of once per search
@@ -1013,14 +1015,16 @@ void ifft_kernel(IfftArgs a) {
         if (lowest != 0x7fffffff)
             atomicMin(a.gkeys + a.first_search + k, make_key(lmin_s + e_pair, (unsigned)((int64_t)lowest + shift)));
     }
-    // the pair's audit run: FFT_AUDIT consecutive positions at a pseudo-random place (a hash of the pair index) leave with their
-    // plain f32 scores whether or not they are candidates; refine_kernel evaluates the runs of AUDIT_PAIRS pairs per search
-    // exactly (consecutive positions: their windows are one another's but for a sample, so a run costs the loads of ONE position)
+    // the pair's audit runs: AUDIT_RUNS x FFT_AUDIT consecutive positions at a pseudo-random place (a hash of the pair index)
+    // leave with their plain f32 scores whether or not they are candidates; refine_kernel evaluates AUDIT_RUNS runs per search
+    // exactly, from as many different transformed pairs as there are (consecutive positions: their windows are one another's but
+    // for a few samples, so a run costs the loads of ONE position)
     {
+        constexpr int RUNP = AUDIT_RUNS * FFT_AUDIT;                     // FT % RUNP == 0: one r, one half for the whole stretch
         const unsigned h = ((unsigned)(a.sub_first_pair + pr) * 2654435761u) >> 7;
-        const int pos_a = FFT_AUDIT * (int)(h % (unsigned)(2 * FH / FFT_AUDIT));      // the run's first position; FT % FFT_AUDIT == 0: one r, one half
+        const int pos_a = RUNP * (int)(h % (unsigned)(2 * FH / RUNP));
         const int j = tid - pos_a % FT;
-        if (j >= 0 && j < FFT_AUDIT) {
+        if (j >= 0 && j < RUNP) {
             const int qa = (pos_a / FH) * HPT + (pos_a % FH) / FT;
             float sc = __builtin_inff();
 #pragma unroll
@@ -1028,6 +1032,188 @@ void ifft_kernel(IfftArgs a) {
             if (sc >= 0.f && sc < __builtin_inff()) cout[FFT_CAND + 2 + j] = make_key(sc, (unsigned)((int64_t)(pos_a + j) + shift));
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Which block pairs need no inverse transform at all.
+//
+// A position can be the search's arg-min only if its score is not above U, the smallest (f32 score + bound) any pair of the
+// search has reported.  bound_kernel gives every pair a LOWER bound of the exact scores of all its positions without scoring
+// any of them:
+//   * the cross term: after the three passes of the inverse transform that stay inside a wave (no LDS exchange, no barrier),
+//     wave n1 holds A_n1[k2], the 1024-point transform of its decimated share of Y, and every output of the full transform is
+//     a sum of sixteen of them times unit factors: |y[r]| <= B = sum_n1 max_k2 |A_n1[k2]|.  For a pair that does not hold the
+//     match the A are noise and B is a fifth of what the matching pair's is;
+//   * the window energies: sum I^2 over [p, p + M) >= S2[(j + M / G) G] - S2[(j + 1) G] for every p of the G-sample stretch j
+//     (a table of the prefix at every G = COARSE_G-th sample, built once per stream); wlb = the smallest over the pair's
+//     stretches that hold a valid position;
+//   * score(p) = (sum T^2 + wU - 2 sum T I) / (|T| sqrt(wU)) increases with wU and decreases with sum T I, so
+//         slb = (tU' + wlb - 2 Ymax) / (|T| sqrt(wlb)),   Ymax = B / scale + the cross term's modelled error (pair_error_model)
+//     is below every exact score of the pair.
+// pilot_kernel then picks, per search, the pair with the smallest slb -- where the match is if there is one --, ifft_kernel
+// transforms and scores those (one workgroup per search) and leaves U; survivor_kernel lists the pairs with slb <= U, which are
+// transformed as before; all others are done: slb > U means every exact score of the pair is above the exact score of a position
+// already found.  (U >= 1 -- nothing matches anywhere, every score clamps to 1 and TIES -- excludes nothing.)
+// ------------------------------------------------------------------------------------------
+struct BoundArgs {
+    const uint2* y;
+    const double* dst_stats;
+    const SearchDesc* searches;       // the sub-batch's searches
+    int sub_first_pair;
+    int first_search;
+    int64_t dst_len;
+    const int* pairmap;
+    const TemplConsts* tconst;
+    const double* ubase;
+    const double* sbase;
+    int64_t nb;
+    const double* coarse;             // [nc] s2 at every COARSE_G-th sample
+    int64_t nc;
+    float* slb;                       // [pairs of the sub-batch] out: lower bound of the pair's exact scores (-inf: none)
+    // pilot / survivor stages
+    int n_sub;
+    int n_pairs;
+    int* plist;                       // [searches of the sub-batch] the pair transformed first
+    int* slist;                       // [pairs of the sub-batch] the pairs still to transform
+    int* scount;                      // [1]
+    const int* order;                 // the L2-friendly schedule of all pairs (survivors keep its order)
+    const unsigned long long* gkeys;  // [all searches]
+    float* pair_lb;
+    RunCounters* counters;
+};
+
+__global__ __launch_bounds__(FT, 8)
+void bound_kernel(BoundArgs a) {
+    __shared__ float red_b[FT / 64], red_q[FT / 64], red_w[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pr = blockIdx.x;
+    sushi_fft::uint4v yl[4];
+    const float q2 = load_y(yl, a.y + (size_t)pr * (FN / 2), tid);
+    const sushi_fft::MfmaB mb = dft16_operands(tid);
+    const sushi_fft::WTwiddles tw = sushi_fft::load_wtwiddles<1>(tid, twiddles());
+    const int k = __builtin_amdgcn_readfirstlane(a.pairmap[pr]);
+    const SearchDesc sd = a.searches[k];
+    const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
+    const int64_t pairI = lay.pair0 + (a.sub_first_pair + pr - sd.first_pair);
+    const int64_t qbase = pairI * FFT_STEP * (int64_t)FFT_SEG;
+    const int M = sd.tmpl_len;
+    // Everything of the bound that does not need the transform, from wave-uniform (scalar) loads issued here: a workgroup's last
+    // thread standing must not start a chain of dependent loads when the other 1023 are done (it held the CU's slot for it).
+    const TemplConsts tc = a.tconst[k];
+    const int64_t kA = pairI * FFT_STEP;
+    const int n_seg = lay.n_seg;
+    const int64_t n = a.dst_len;
+    double err_y, tU2;
+    {
+        // energy of the CENTRED samples that enter this pair's transforms (score_pair's zn_c)
+        const int64_t iA = kA < a.nb ? kA : a.nb, iB = kA + n_seg + 2 * FFT_VB < a.nb ? kA + n_seg + 2 * FFT_VB : a.nb;
+        const double u0 = a.ubase[iA], u1 = a.ubase[iB], s0 = a.sbase[iA], s1 = a.sbase[iB];
+        const int64_t s_lo = qbase < n ? qbase : n;
+        const int64_t s_hi64 = (kA + n_seg + 2 * FFT_VB) * (int64_t)FFT_SEG;
+        const int64_t s_hi = s_hi64 < n ? s_hi64 : n;
+        const double c = a.dst_stats[1];
+        const double e2 = (u1 - u0) - 2.0 * c * (s1 - s0) + c * c * (double)(s_hi - s_lo);
+        const double zn_c = sqrt(fmax(e2, 0.0)) * 1.0000005;
+        err_y = 5.9604645e-8 * (double)FFT_KE * zn_c * (double)tc.tnorm;       // the FFT stage's error of the cross term
+        tU2 = tc.tU - 2.0 * (double)tc.c_sum_t;
+    }
+    cpx v[sushi_fft::PER];
+    sushi_fft::fft_wave_mfma_front<1>(yl, v, tid, tw, mb);
+    float m2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < sushi_fft::PER; ++r) m2 = fmaxf(m2, __builtin_fmaf(v[r].x, v[r].x, v[r].y * v[r].y));
+    const float wm = wave_max_f32(m2), qw = wave_sum_f32(q2);
+    if (lane == 0) { red_b[wave] = sqrtf(wm) * 1.000002f; red_q[wave] = qw; }
+    // lower bound of the window energies: the stretches of COARSE_G positions that hold a valid position of the search
+    constexpr int NSB = 2 * FH / COARSE_G;
+    static_assert(NSB <= 128 && (FFT_STEP * FFT_SEG) % COARSE_G == 0, "two waves look the stretches up");
+    if (wave < 2) {
+        const int64_t plo = sd.win_start - qbase, phi = (int64_t)sd.n_pos + (sd.win_start - qbase);   // valid: plo <= pos < phi
+        float wl = __builtin_inff();
+        const int64_t p0 = (int64_t)tid * COARSE_G;
+        if (tid < NSB && p0 + COARSE_G > plo && p0 < phi) {
+            const int64_t j = qbase / COARSE_G + tid;
+            int64_t je = j + M / COARSE_G, js = j + 1;
+            je = je < a.nc - 1 ? je : a.nc - 1;
+            js = js < a.nc - 1 ? js : a.nc - 1;
+            const double e = je > js ? a.coarse[je] - a.coarse[js] : 0.0;
+            wl = fmaxf((float)e * 0.9999995f, 0.f);
+        }
+        const float wmin = wave_min_f32(wl);
+        if (lane == 0) red_w[wave] = wmin;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float B = 0.f, qmax = 0.f;
+#pragma unroll
+        for (int w = 0; w < FT / 64; ++w) { B += red_b[w]; qmax = fmaxf(qmax, red_q[w]); }
+        const float wlb = fminf(red_w[0], red_w[1]);
+        const int mac_passes = (n_seg + MAC_SMAX_LONG - 1) / MAC_SMAX_LONG;
+        const double sigma_y = sqrt((double)((float)(FT / 64) * qmax) * (7.9472862e-8 * (double)(2 + mac_passes)) + (double)FN * 1.2e-15) *
+                               (double)tc.inv_scale;
+        // what the exact centred cross term of any position of this pair can reach: the bound of the transform's outputs (its
+        // own float32 rounding included in the factor), the FFT stage's error, the packed halves' modelled error
+        const double ymax = (double)B * (double)tc.inv_scale * 1.00002 + err_y + (double)Y_KQ * sigma_y;
+        const double a0 = tU2 - 2.0 * ymax;
+        float slb = -__builtin_inff();
+        if (wlb > 0.f && wlb < __builtin_inff() && a0 < (double)wlb && tc.tU > 0.0)
+            slb = (float)((a0 + (double)wlb) / (sqrt((double)wlb) * (double)tc.tnorm) * 0.999999);
+        a.slb[pr] = slb;
+    }
+}
+
+// per search: the pair with the smallest lower bound (the first of them) is transformed first
+__global__ __launch_bounds__(64)
+void pilot_kernel(BoundArgs a) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const SearchDesc sd = a.searches[k];
+    const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
+    const int p0 = sd.first_pair - a.sub_first_pair;
+    unsigned long long best = NO_KEY;
+    for (int i = lane; i < lay.n_pairs; i += 64) {
+        const float s = a.slb[p0 + i];
+        // order-preserving key of a float that may be negative or -inf
+        const unsigned b = __float_as_uint(s);
+        const unsigned ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+        const unsigned long long key = ((unsigned long long)ord << 32) | (unsigned)i;
+        best = key < best ? key : best;
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) {
+        a.plist[k] = p0 + (int)(best & 0xffffffffull);
+        if (k == 0) *a.scount = 0;
+        atomicAdd(&a.counters->pairs_transformed, 1ull);
+    }
+}
+
+// every pair but the pilots: excluded (its lower bound is above what the search has already found: pair_lb = +inf, what
+// refine_kernel and collect_kernel skip by), or listed for ifft_kernel in the order of the L2-friendly schedule
+__global__ __launch_bounds__(256)
+void survivor_kernel(BoundArgs a) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    int pr = 0;
+    if (b < a.n_pairs) {
+        pr = a.order[b];
+        const int k = a.pairmap[pr];
+        if (a.plist[k] != pr) {
+            const unsigned long long g = a.gkeys[a.first_search + k];
+            const float U = g == NO_KEY ? __builtin_inff() : key_score(g);
+            // (a search whose best score is 1 -- no match anywhere, every score clamped to 1 -- ties everywhere: nothing is excluded)
+            const bool excluded = U < 0.9999f && a.slb[pr] > U * 1.000001f + 1e-7f;
+            if (excluded) a.pair_lb[pr] = __builtin_inff();
+            keep = !excluded;
+        }
+    }
+    const unsigned long long m = __ballot(keep);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && m) {
+        base = atomicAdd(a.scount, __popcll(m));
+        atomicAdd(&a.counters->pairs_transformed, (unsigned long long)__popcll(m));
+    }
+    base = __shfl(base, 0, 64);
+    if (keep) a.slist[base + __popcll(m & ((1ull << lane) - 1ull))] = pr;
 }
 
 // Collection pass over the flagged searches of a sub-batch: the same transforms and scores again (bit for bit), now
@@ -1153,7 +1339,7 @@ inline int64_t cand_capacity(int64_t pairs) {
 }
 
 // bytes of workspace for one sub-batch of `pairs` block pairs, `segs` pattern segments and `searches` searches
-struct WsLayout { size_t tspec, y, cand, pair_lb, pairmap, tconst, tiles, candbuf, dummy, total; };
+struct WsLayout { size_t tspec, y, cand, pair_lb, pairmap, tconst, tiles, candbuf, dummy, slb, plist, slist, scount, total; };
 inline WsLayout ws_layout(int64_t pairs, int64_t segs, int64_t searches) {
     WsLayout w;
     size_t o = 0;
@@ -1166,6 +1352,10 @@ inline WsLayout ws_layout(int64_t pairs, int64_t segs, int64_t searches) {
     w.tiles = o; o += align_up((size_t)pairs * TILES_PER_PAIR * sizeof(TileDesc), 256);
     w.candbuf = o; o += align_up((size_t)cand_capacity(pairs) * sizeof(int32_t), 256);
     w.dummy = o; o += align_up((size_t)MAC_DUMMY_LINES * MAC_THREADS * sizeof(uint4), 256);
+    w.slb = o; o += align_up((size_t)pairs * sizeof(float), 256);
+    w.plist = o; o += align_up((size_t)searches * sizeof(int), 256);
+    w.slist = o; o += align_up((size_t)pairs * sizeof(int), 256);
+    w.scount = o; o += 256;
     w.total = o;
     return w;
 }
@@ -1630,11 +1820,37 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         ia.usrel = dst->usrel; ia.sbase = dst->base + (dst->blocks + 1);
         ia.flags = flags; ia.flag_list = flag_list; ia.sub_flagged = sub_flagged; ia.tiles = tiles; ia.candbuf = candbuf;
         ia.cand_cap = (int)cand_capacity(sbt.pairs); ia.counters = counters;
-        if (b->method == SUSHI_HIP_METHOD_CCOEFF_NORMED)
+        if (b->method == SUSHI_HIP_METHOD_CCOEFF_NORMED) {
             hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3((unsigned)sbt.pairs), dim3(FT), 0, st, ia);
-        else
-            hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3((unsigned)sbt.pairs), dim3(FT), 0, st, ia);
-        if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+        } else {
+            // TM_SQDIFF_NORMED: a lower bound of every pair's scores first (three of the transform's four passes, no scoring);
+            // then the most promising pair of every search, which leaves the search's threshold; then whatever the bound
+            // could not exclude (header of bound_kernel)
+            BoundArgs ba;
+            memset(&ba, 0, sizeof(ba));
+            ba.y = (const uint2*)y; ba.dst_stats = dst->stats; ba.searches = searches_dev + sbt.a0; ba.sub_first_pair = sbt.first_pair;
+            ba.first_search = sbt.a0; ba.dst_len = dst->n; ba.pairmap = pairmap; ba.tconst = tconst; ba.ubase = dst->base;
+            ba.sbase = dst->base + (dst->blocks + 1); ba.nb = dst->blocks; ba.coarse = dst->coarse; ba.nc = dst->nc;
+            ba.slb = (float*)(wsp + wl.slb); ba.n_sub = n_sub; ba.n_pairs = (int)sbt.pairs; ba.plist = (int*)(wsp + wl.plist);
+            ba.slist = (int*)(wsp + wl.slist); ba.scount = (int*)(wsp + wl.scount); ba.order = order + sbt.first_pair;
+            ba.gkeys = gkeys; ba.pair_lb = pair_lb; ba.counters = counters;
+            hipLaunchKernelGGL(bound_kernel, dim3((unsigned)sbt.pairs), dim3(FT), 0, st, ba);
+            if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            prof_end(pc, t0, SUSHI_HIP_STAGE_BOUND, st);
+            t0 = prof_begin(pc, st);
+            hipLaunchKernelGGL(pilot_kernel, dim3((unsigned)n_sub), dim3(64), 0, st, ba);
+            if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            IfftArgs ip = ia;
+            ip.order = ba.plist; ip.count = nullptr;
+            hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3((unsigned)n_sub), dim3(FT), 0, st, ip);
+            if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            hipLaunchKernelGGL(survivor_kernel, dim3((unsigned)((sbt.pairs + 255) / 256)), dim3(256), 0, st, ba);
+            if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            ip.order = ba.slist; ip.count = ba.scount;
+            hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3((unsigned)sbt.pairs), dim3(FT), 0, st, ip);
+            if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+        }
         prof_end(pc, t0, SUSHI_HIP_STAGE_IFFT, st);
 
         t0 = prof_begin(pc, st);
@@ -1684,6 +1900,7 @@ int sushi_hip_batch_diagnostics(SushiHipBatch* b, SushiHipBatchDiag* diag, float
     memcpy(&diag->max_bound_ratio, &c.max_ratio_bits, sizeof(float));
     memcpy(&diag->max_bound_ratio_noncandidate, &c.max_ratio_audit_bits, sizeof(float));
     diag->audited = (int64_t)c.audited;
+    diag->pairs_transformed = (int64_t)c.pairs_transformed;
     std::vector<int32_t> fl((size_t)b->n);
     if (hipMemcpy(fl.data(), b->mem + b->lay.flags, (size_t)b->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
         return SUSHI_HIP_ELAUNCH;

@@ -434,9 +434,9 @@ __global__ void unpack_keys_kernel(const unsigned long long* __restrict__ keys, 
 // search, which is then evaluated at every position (flag 2).  One workgroup per search.
 // ------------------------------------------------------------------------------------------
 constexpr int RCAP = 128;
-constexpr int RAUD = AUDIT_PAIRS * FFT_AUDIT;     // audited non-candidate positions per search
+constexpr int RAUD = AUDIT_RUNS * FFT_AUDIT;      // audited non-candidate positions per search
 constexpr int RENT = RCAP + RAUD;                // list entries: candidates, then audit positions
-constexpr int REFINE_THREADS = 384;              // thread <-> (task, chunk): the usual search (one candidate + AUDIT_PAIRS runs, a 3 s pattern = 71 chunks) in one round
+constexpr int REFINE_THREADS = 384;              // thread <-> (task, chunk): the usual search (one candidate + AUDIT_RUNS runs, a 3 s pattern = 71 chunks) in one round
 
 // Entries [0, n_cand) of the list are candidates; entries [n_cand, n_all) are audit positions: NOT selected, with their plain
 // f32 scores, evaluated like the others and only checked against the bound (the two-sided check of the error model).
@@ -569,23 +569,27 @@ void refine_kernel(RefineParams a) {
         }
     }
     if (!ovf) {
-        // AUDIT_PAIRS x FFT_AUDIT positions per search that are NOT candidates: the audit runs of pairs picked by a hash of the
-        // search index, spread over the window; evaluated exactly like the candidates and held to the same bound (the check of
-        // the error model where it was not already believed).  A run of FFT_AUDIT valid positions is one task; a run cut by the
-        // window's edge gives its valid positions one by one.
+        // AUDIT_RUNS x FFT_AUDIT positions per search that are NOT candidates: audit runs of the pairs that were transformed (a pair
+        // the bound excluded has no scores), from as many different pairs as there are -- starting at a hash of the search index;
+        // evaluated exactly like the candidates and held to the same bound (the check of the error model where it was not already
+        // believed).  A run of FFT_AUDIT valid positions is one task; a run cut by the window's edge gives its valid positions
+        // one by one.
         for (int t = tid; t < n; t += REFINE_THREADS) { tent[t] = (short)t; tlen[t] = 1; }
         if (tid == 0) {
             int n_all = n, n_tasks = n;
             const unsigned h = (unsigned)s_idx * 2654435761u;
-            const int n_ap = lay.n_pairs < AUDIT_PAIRS ? lay.n_pairs : AUDIT_PAIRS;
-            const int step = lay.n_pairs / n_ap;
             const int pa0 = (int)((h >> 8) % (unsigned)lay.n_pairs);
-            for (int j = 0; j < n_ap; ++j) {
-                const int pa = (pa0 + j * step) % lay.n_pairs;
+            int sel[AUDIT_RUNS], n_sel = 0;
+            for (int j = 0; j < lay.n_pairs && n_sel < AUDIT_RUNS; ++j) {
+                const int pa = pa0 + j < lay.n_pairs ? pa0 + j : pa0 + j - lay.n_pairs;
+                if (rows[(size_t)pa * FFT_ROW + FFT_CAND + 1] != NO_KEY) sel[n_sel++] = pa;      // transformed: it left its error bound
+            }
+            for (int r = 0; r < AUDIT_RUNS && n_sel > 0; ++r) {
+                const int pa = sel[r % n_sel], run = r / n_sel;
                 unsigned long long key[FFT_AUDIT];
                 int valid = 0;
                 for (int q = 0; q < FFT_AUDIT; ++q) {
-                    key[q] = rows[(size_t)pa * FFT_ROW + FFT_CAND + 2 + q];
+                    key[q] = rows[(size_t)pa * FFT_ROW + FFT_CAND + 2 + run * FFT_AUDIT + q];
                     valid += key[q] != NO_KEY ? 1 : 0;
                 }
                 if (valid == FFT_AUDIT) { tent[n_tasks] = (short)n_all; tlen[n_tasks] = FFT_AUDIT; ++n_tasks; }
@@ -810,6 +814,18 @@ void final_scan_kernel(const T* __restrict__ raw, int64_t n, const double* __res
     }
 }
 
+// s2 and s1 at every COARSE_G-th sample (entries past the end: the totals) -- a table small enough to live in the L2s, from which
+// bound_kernel takes a lower bound of the window energies of a whole block pair
+__global__ void coarse_prefix_kernel(const double* __restrict__ s1, const double* __restrict__ s2, int64_t n, int64_t nc,
+                                     double* __restrict__ coarse) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nc) {
+        const int64_t e = j * COARSE_G < n ? j * COARSE_G : n;
+        coarse[j] = s2[e];
+        coarse[nc + j] = s1[e];
+    }
+}
+
 // What the FFT path needs to know about a stream as a whole (sushi_fft.hip, "packed halves"): the constant its block
 // spectra are centred by -- the stream's own mean, as a float: any constant is exact (sum T I = sum T (I - c) + c sum T),
 // the mean keeps DC out of the products whatever level the data sits at -- and the largest centred energy of FFT_STEP + 1
@@ -903,7 +919,7 @@ namespace {
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // where the parts of a prepared stream go inside the caller's buffer
-struct StreamLayout { size_t xc, s1, s2, urel, srel, base, base_bytes, spec, total; };
+struct StreamLayout { size_t xc, s1, s2, urel, srel, base, base_bytes, coarse, spec, total; };
 
 StreamLayout stream_layout(int64_t n, int searchable) {
     StreamLayout l;
@@ -916,6 +932,7 @@ StreamLayout stream_layout(int64_t n, int searchable) {
     l.srel = o; o += align_up((size_t)(n + 1) * 2 * sizeof(float), 256);     // usrel: (urel, srel) interleaved
     l.base_bytes = (size_t)(2 * (nb + 1) + 2) * sizeof(double);  // block bases of sum x^2, then of sum x, then the FFT path's stats
     l.base = o; o += align_up(l.base_bytes, 256);
+    l.coarse = o; o += align_up((size_t)2 * (size_t)(n / COARSE_G + 2) * sizeof(double), 256);
     l.spec = o; o += searchable ? align_up(sushi_hip_stream_spectra_bytes(n), 256) : 0;
     l.total = o;
     return l;
@@ -975,6 +992,7 @@ int sushi_hip_stream_create(const void* raw_dev, int dtype, int64_t n, int searc
     s->xc = (float*)(m + l.xc); s->s1 = (double*)(m + l.s1); s->s2 = (double*)(m + l.s2);
     s->urel = (float*)(m + l.urel); s->usrel = (float*)(m + l.srel); s->base = (double*)(m + l.base); s->base_bytes = l.base_bytes;
     s->spec = nullptr; s->spec_bytes = 0; s->blocks = nb; s->stats = s->base + 2 * (nb + 1);
+    s->coarse = (double*)(m + l.coarse); s->nc = n / COARSE_G + 2;
     hipStream_t st = (hipStream_t)hip_stream;
     double* bs2 = s->base;                       // block bases of sum x^2 (what the FFT path's scoring reads)
     double* bs1 = s->base + (nb + 1);            // block bases of sum x
@@ -1000,6 +1018,11 @@ int sushi_hip_stream_create(const void* raw_dev, int dtype, int64_t n, int searc
     }
     if (rc == SUSHI_HIP_OK) {
         hipLaunchKernelGGL(fft_stats_kernel, dim3(1), dim3(1024), 0, st, (const double*)bs2, (const double*)bs1, nb, n, s->stats);
+        rc = launch_ok();
+    }
+    if (rc == SUSHI_HIP_OK) {
+        hipLaunchKernelGGL(coarse_prefix_kernel, dim3((unsigned)((s->nc + 255) / 256)), dim3(256), 0, st, (const double*)s->s1,
+                           (const double*)s->s2, n, s->nc, s->coarse);
         rc = launch_ok();
     }
     if (rc == SUSHI_HIP_OK && searchable)

@@ -20,6 +20,9 @@ struct SushiHipStream {
     float* usrel;             // [n + 1][2]  (urel[e], s1 relative to the block base): TM_CCOEFF_NORMED on the FFT path, one 8-byte load per window end
     double* base;             // [nb + 1] block bases of s2, then [nb + 1] block bases of s1, then `stats`
     double* stats;            // [2] FFT path: largest centred energy of seven consecutive blocks; the centring constant
+    double* coarse;           // [2][nc] s2 and s1 at every COARSE_G-th sample (nc = n / COARSE_G + 2; entries past the end hold the
+                              //         totals): bound_kernel's lower bound of a block pair's window energies
+    int64_t nc;
     size_t base_bytes;
     void* spec;               // [(nb + 1) * N] complex f32 block spectra, or null
     size_t spec_bytes;
@@ -66,6 +69,7 @@ struct RunCounters {
     uint32_t max_ratio_bits;  // float bits of SushiHipBatchDiag.max_bound_ratio
     uint32_t max_ratio_audit_bits;  // float bits of SushiHipBatchDiag.max_bound_ratio_noncandidate
     unsigned long long audited;     // non-candidate positions evaluated exactly (SushiHipBatchDiag.audited)
+    unsigned long long pairs_transformed;   // block pairs whose inverse transform was run (the others were excluded by bound_kernel's bound)
 };
 
 int direct_variant_count();
