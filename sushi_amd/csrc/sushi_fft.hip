@@ -220,6 +220,7 @@ struct TspecArgs {
     const double* src_s2;
     double centre;
     const double* dst_stats;          // the searched stream's stats: [0] largest energy of a pair's span, [1] its centring constant
+    int method;                       // SUSHI_HIP_METHOD_CCOEFF_NORMED: spectra of the pattern minus its own mean
 };
 
 template <typename T>
@@ -234,8 +235,14 @@ void tspec_kernel(TspecArgs a) {
     const int s = seg - sd.first_seg;
     const int M = sd.tmpl_len;
     const TemplStats ts_all = templ_stats(a.src_s1, a.src_s2, sd.tmpl_off, M, a.centre);
-    const float y_scale = y_scale_for(ts_all.tnorm, (M + FFT_SEG - 1) / FFT_SEG, a.dst_stats[0]);
-    const float t_scale = t_scale_for(ts_all.tnorm);
+    // TM_CCOEFF_NORMED correlates the pattern MINUS ITS OWN MEAN: sum (T - mean T) I is that method's numerator as it is (no
+    // window-sum term left to subtract, nothing of the pattern's level in the products), and what the spectra hold -- and the
+    // scales are sized by -- is the centred pattern's norm.  (A pattern without variance is answered without its spectra.)
+    const bool cc = a.method == SUSHI_HIP_METHOD_CCOEFF_NORMED;
+    const double tn_spec = cc && !ts_all.flat ? ts_all.tnorm_c : ts_all.tnorm;
+    const float t_sub = cc ? (float)ts_all.tmean : 0.f;
+    const float y_scale = y_scale_for(tn_spec, (M + FFT_SEG - 1) / FFT_SEG, a.dst_stats[0]);
+    const float t_scale = t_scale_for(tn_spec);
     if (s == 0) {
         const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, M);
         int* __restrict__ pm = a.pairmap + (sd.first_pair - a.sub_first_pair);
@@ -246,7 +253,8 @@ void tspec_kernel(TspecArgs a) {
             tc.tU = ts.tU; tc.inv_tnorm = (float)(1.0 / ts.tnorm); tc.tnorm = (float)ts.tnorm;
             tc.tmean = (float)ts.tmean; tc.flat = ts.flat ? 1 : 0;
             tc.inv_tnorm_c = ts.flat ? 0.f : (float)(1.0 / ts.tnorm_c); tc.inv_m = (float)(1.0 / (double)M);
-            tc.c_sum_t = (float)(a.dst_stats[1] * ts.tS1); tc.inv_scale = 1.0f / y_scale;
+            tc.c_sum_t = cc ? 0.f : (float)(a.dst_stats[1] * ts.tS1);      // (the centred pattern sums to zero)
+            tc.inv_scale = 1.0f / y_scale;
             tc.mac_scale = (float)((double)y_scale / ((double)t_scale * (double)z_scale_for(a.dst_stats[0])));
             a.tconst[k] = tc;
         }
@@ -257,7 +265,7 @@ void tspec_kernel(TspecArgs a) {
 #pragma unroll
     for (int r = 0; r < sushi_fft::PER; ++r) {
         const int e = sushi_fft::in_index<FFT_LOGN>(tid, r);
-        const float xa = (float)t[e < len ? e : len - 1];
+        const float xa = (float)t[e < len ? e : len - 1] - t_sub;
         v[r].x = e < len ? xa : 0.f;
         v[r].y = 0.f;
     }
@@ -570,12 +578,11 @@ struct PairScores {
 };
 
 // constants of the TM_CCOEFF_NORMED error model, in units of eps = 2^-24:
-//   numerator   corr - wS1 * tmean : |err| <= eps * |T| * |Z| * (FFT_KE + 8 + 256 / sqrt(M))
+//   numerator   sum (T - mean T) I : |err| <= eps * |T_c| * |Z| * FFT_KE   (the cross term of the centred pattern as it is)
 //   variance    wU - wS1^2 / M     : |err| <= eps * |Z|^2 * CD,  CD = 28 + 512 / sqrt(M)
 // (|Z|^2 = the energy of the samples that enter the pair's transforms; window sums come from float32 prefix values
 // relative to per-block float64 bases: each of them is off by <= eps * 64 |Z|, wS1 <= sqrt(M) |Z|, tmean <= |T| / sqrt(M)).
 __device__ __forceinline__ float ccoeff_cd(float inv_sqrt_m) { return 28.0f + 512.0f * inv_sqrt_m; }
-__device__ __forceinline__ float ccoeff_kn(float inv_sqrt_m) { return FFT_KE + 8.0f + 256.0f * inv_sqrt_m; }
 
 // Y of one pair (packed halves) into the registers of the inverse transform.  Y is stored in the order the transform loads
 // it: one 16-byte load brings four registers, a wave's load instruction one contiguous KiB.  Issued before anything else a
@@ -782,9 +789,7 @@ __device__ __forceinline__ void score_pair(const IfftArgs& a, const sushi_fft::u
     const float tU = uniform((float)(tc.tU - 2.0 * (double)tc.c_sum_t));
     const float m2s = uniform(-2.0f * tc.inv_scale);
     const float inv_s = uniform(tc.inv_scale);
-    const float cst = uniform(tc.c_sum_t);
     const float inv_tnorm = uniform(CC ? tc.inv_tnorm_c : tc.inv_tnorm);
-    const float tmean = uniform(tc.tmean);
     const float neg_inv_m = uniform(-tc.inv_m);
     // (METHOD 1) a window variance sum below this is inside its own rounding error: four times the modelled error
     const float tau = uniform(4.0f * 5.9604645e-8f * zn * zn * ccoeff_cd(sqrtf(tc.inv_m)));
@@ -817,8 +822,7 @@ __device__ __forceinline__ void score_pair(const IfftArgs& a, const sushi_fft::u
                 bool certain;
                 if (CC) {
                     const float wS = (us0[half][blk] + (carry ? dus[half][blk] : 0.f)) + (sb_[q] - sa[q]);   // sum I
-                    const float corr = __builtin_fmaf(yv, inv_s, cst);               // sum T I
-                    const float num = __builtin_fmaf(-wS, tmean, corr);              // sum T I - sum I * mean T
+                    const float num = yv * inv_s;                                    // sum (T - mean T) I: the spectra are of the centred pattern
                     const float d2 = __builtin_fmaf(wS * neg_inv_m, wS, wU);         // sum I^2 - (sum I)^2 / M
                     certain = d2 > tau;
                     rs = __builtin_amdgcn_rsqf(d2);
@@ -888,8 +892,8 @@ __device__ __forceinline__ float pair_error_model(float zn, float zn_c, float ma
     if (METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED) {
         const float ism = sqrtf(tc.inv_m);
         const float z = fmaxf(zn, zn_c);
-        return eps * max_rs * z * (tc.tnorm * tc.inv_tnorm_c * ccoeff_kn(ism) + ccoeff_cd(ism) * z * max_rs) +
-               Y_KQ * sigma_y * max_rs * tc.inv_tnorm_c;
+        // (numerator: the cross term of the CENTRED pattern, FFT_KE eps |T_c| |Z|, over |T_c| |W_c|)
+        return eps * max_rs * z * (FFT_KE + ccoeff_cd(ism) * z * max_rs) + Y_KQ * sigma_y * max_rs * tc.inv_tnorm_c;
     }
     return eps * max_rs * (2.0f * FFT_KE * zn_c + 16.0f * zn * zn * tc.inv_tnorm) + 2.0f * Y_KQ * sigma_y * max_rs * tc.inv_tnorm;
 }
@@ -1070,6 +1074,7 @@ struct BoundArgs {
     const double* coarse;             // [nc] s2 at every COARSE_G-th sample
     int64_t nc;
     float* slb;                       // [pairs of the sub-batch] out: lower bound of the pair's exact scores (-inf: none)
+    float* acc;                       // [pairs of the sub-batch][2] bound_kernel's accumulators: sum of the waves' max |A|, largest wave row energy
     // pilot / survivor stages
     int n_sub;
     int n_pairs;
@@ -1082,82 +1087,151 @@ struct BoundArgs {
     RunCounters* counters;
 };
 
-__global__ __launch_bounds__(FT, 8)
+// Stage 1: the transform part.  An item = (pair, n1): one wave's decimated share of one pair's Y (4 KB), three passes, the
+// largest |A_n1[k2]|.  Waves are persistent and free-running -- no workgroup-wide step: every wave walks its own items and
+// requests the next item's Y before it transforms the current one, so that the HBM stream never waits for a transform (with
+// one workgroup per pair, all sixteen waves loading and then all sixteen transforming, it ran at half the rate).  Neighbouring
+// waves take neighbouring items: the sixteen shares of a pair are read at about the same time.  Results are added to the pair's
+// accumulators (zeroed by a memset): acc[2 pr] += max |A|, acc[2 pr + 1] = max(row energy of a wave) as float bits.
+constexpr int BOUND_THREADS = 256;
+__global__ __launch_bounds__(BOUND_THREADS, 3)
 void bound_kernel(BoundArgs a) {
-    __shared__ float red_b[FT / 64], red_q[FT / 64], red_w[2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pr = blockIdx.x;
-    sushi_fft::uint4v yl[4];
-    const float q2 = load_y(yl, a.y + (size_t)pr * (FN / 2), tid);
-    const sushi_fft::MfmaB mb = dft16_operands(tid);
-    const sushi_fft::WTwiddles tw = sushi_fft::load_wtwiddles<1>(tid, twiddles());
+    const int lane = threadIdx.x & 63;
+    const int waves = gridDim.x * (BOUND_THREADS / 64);
+    const int gw = blockIdx.x * (BOUND_THREADS / 64) + (threadIdx.x >> 6);
+    const int64_t n_items = (int64_t)a.n_pairs * 16;
+    // the transform's per-lane constants do not depend on the wave (tw.p4, which does, belongs to the pass that is not run)
+    const sushi_fft::MfmaB mb = dft16_operands(lane);
+    const sushi_fft::WTwiddles tw = sushi_fft::load_wtwiddles<1>(lane, twiddles());
+    const sushi_fft::uint4v* __restrict__ yh = reinterpret_cast<const sushi_fft::uint4v*>(a.y);
+    auto load_item = [&](const int64_t it, sushi_fft::uint4v (&yl)[4]) {
+        const size_t pr = (size_t)(it >> 4);
+        const int n1 = (int)(it & 15);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) yl[u] = yh[pr * (FN / 4) + sushi_fft::wslot_uint4(n1 * 64 + lane, u)];
+    };
+    int64_t it = gw;
+    if (it >= n_items) return;
+    sushi_fft::uint4v yl[4], yn[4];
+    load_item(it, yl);
+    for (; it < n_items; it += waves) {
+        const int64_t nx = it + waves < n_items ? it + waves : it;       // (the last item re-requests itself: unconditional loads)
+        load_item(nx, yn);
+        __builtin_amdgcn_sched_barrier(0);      // (left to itself the scheduler sinks these loads to the end of the loop body: no prefetch at all)
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        float q2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const h2 h = __builtin_bit_cast(h2, yl[u][j]);
+                q2 = __builtin_amdgcn_fdot2(h, h, q2, false);
+            }
+        cpx v[sushi_fft::PER];
+        sushi_fft::fft_wave_mfma_front<1>(yl, v, lane, tw, mb);
+        float m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < sushi_fft::PER; ++r) m2 = fmaxf(m2, __builtin_fmaf(v[r].x, v[r].x, v[r].y * v[r].y));
+        const float wm = wave_max_f32(m2), qw = wave_sum_f32(q2);
+        if (lane == 0) {
+            const size_t pr = (size_t)(it >> 4);
+            atomicAdd(a.acc + 2 * pr, sqrtf(wm) * 1.000002f);
+            atomicMax(reinterpret_cast<unsigned*>(a.acc + 2 * pr + 1), __float_as_uint(qw));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) yl[u] = yn[u];
+    }
+}
+
+// Stage 2: one wave per pair puts the bound together (header above): B and the row energy from the accumulators, the lower
+// bound of the window energies from the coarse table, the FFT stage's error from the block bases.
+// TM_CCOEFF_NORMED (ranked as 1 - cc): cc(p) = sum (T - mean T) I / (|T_c| sqrt(d2(p))) <= Ymax / (|T_c| sqrt(d2lb)) with
+//   d2(p) = sum over the window of (I - c)^2  -  (sum over the window of (I - c))^2 / M          (a variance sum: any c)
+//         >= Ein(j) - (|Din(j)| + sqrt(2 G (Eout(j) - Ein(j))))^2 / M
+// for every p of stretch j: Ein / Din = energy / sum of the centred samples over the G-aligned span inside every such window,
+// Eout = the energy over the G-aligned span around every such window; what a window holds beyond the inner span is at most 2 G
+// samples of at most Eout - Ein energy (Cauchy-Schwarz).  A flat window anywhere in the pair makes d2lb <= 0: nothing excluded.
+template <int METHOD>
+__global__ __launch_bounds__(256)
+void slb_kernel(BoundArgs a) {
+    constexpr bool CC = METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED;
+    const int lane = threadIdx.x & 63;
+    const int pr = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pr >= a.n_pairs) return;
     const int k = __builtin_amdgcn_readfirstlane(a.pairmap[pr]);
     const SearchDesc sd = a.searches[k];
     const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
     const int64_t pairI = lay.pair0 + (a.sub_first_pair + pr - sd.first_pair);
     const int64_t qbase = pairI * FFT_STEP * (int64_t)FFT_SEG;
     const int M = sd.tmpl_len;
-    // Everything of the bound that does not need the transform, from wave-uniform (scalar) loads issued here: a workgroup's last
-    // thread standing must not start a chain of dependent loads when the other 1023 are done (it held the CU's slot for it).
     const TemplConsts tc = a.tconst[k];
     const int64_t kA = pairI * FFT_STEP;
     const int n_seg = lay.n_seg;
     const int64_t n = a.dst_len;
-    double err_y, tU2;
-    {
-        // energy of the CENTRED samples that enter this pair's transforms (score_pair's zn_c)
+    const double c = a.dst_stats[1];
+    // lower bound of the window energies (variance sums): the stretches of COARSE_G positions that hold a valid position
+    constexpr int NSB = 2 * FH / COARSE_G;
+    static_assert(NSB <= 128 && (FFT_STEP * FFT_SEG) % COARSE_G == 0, "a lane looks up two stretches");
+    const int64_t plo = sd.win_start - qbase, phi = (int64_t)sd.n_pos + (sd.win_start - qbase);       // valid: plo <= pos < phi
+    const double* __restrict__ c2 = a.coarse;
+    const double* __restrict__ c1 = a.coarse + a.nc;
+    float wl = __builtin_inff();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int sb = lane + 64 * t;
+        const int64_t p0 = (int64_t)sb * COARSE_G;
+        if (sb < NSB && p0 + COARSE_G > plo && p0 < phi) {
+            const int64_t j = qbase / COARSE_G + sb;
+            auto clampi = [&](int64_t x) { return x < a.nc - 1 ? x : a.nc - 1; };
+            const int64_t js = clampi(j + 1), je = clampi(j + M / COARSE_G);
+            double e = 0.0;
+            if (je > js) {
+                if (CC) {
+                    auto len = [&](int64_t lo, int64_t hi) {
+                        const int64_t x0 = lo * COARSE_G < n ? lo * COARSE_G : n, x1 = hi * COARSE_G < n ? hi * COARSE_G : n;
+                        return (double)(x1 - x0);
+                    };
+                    const int64_t jo0 = clampi(j), jo1 = clampi(j + M / COARSE_G + 2);
+                    const double d_in = (c1[je] - c1[js]) - c * len(js, je);
+                    const double e_in = (c2[je] - c2[js]) - 2.0 * c * (c1[je] - c1[js]) + c * c * len(js, je);
+                    const double e_out = (c2[jo1] - c2[jo0]) - 2.0 * c * (c1[jo1] - c1[jo0]) + c * c * len(jo0, jo1);
+                    const double d_ub = fabs(d_in) + sqrt(2.0 * COARSE_G * fmax(e_out - e_in, 0.0)) * 1.000001 + 1e-6 * (fabs(d_in) + 1.0);
+                    e = e_in * 0.999999 - d_ub * d_ub / (double)M - 1e-9 * (c2[je] - c2[js]);    // (the prefix table's own rounding)
+                } else {
+                    e = c2[je] - c2[js];
+                }
+            }
+            wl = fminf(wl, fmaxf((float)e * 0.9999995f, 0.f));
+        }
+    }
+    const float wlb = wave_min_f32(wl);
+    if (lane == 0) {
+        const float B = a.acc[2 * (size_t)pr], qmax = a.acc[2 * (size_t)pr + 1];
+        // energy of the samples that enter this pair's transforms, as they are (zn) and centred (zn_c): score_pair's
         const int64_t iA = kA < a.nb ? kA : a.nb, iB = kA + n_seg + 2 * FFT_VB < a.nb ? kA + n_seg + 2 * FFT_VB : a.nb;
         const double u0 = a.ubase[iA], u1 = a.ubase[iB], s0 = a.sbase[iA], s1 = a.sbase[iB];
         const int64_t s_lo = qbase < n ? qbase : n;
         const int64_t s_hi64 = (kA + n_seg + 2 * FFT_VB) * (int64_t)FFT_SEG;
         const int64_t s_hi = s_hi64 < n ? s_hi64 : n;
-        const double c = a.dst_stats[1];
         const double e2 = (u1 - u0) - 2.0 * c * (s1 - s0) + c * c * (double)(s_hi - s_lo);
-        const double zn_c = sqrt(fmax(e2, 0.0)) * 1.0000005;
-        err_y = 5.9604645e-8 * (double)FFT_KE * zn_c * (double)tc.tnorm;       // the FFT stage's error of the cross term
-        tU2 = tc.tU - 2.0 * (double)tc.c_sum_t;
-    }
-    cpx v[sushi_fft::PER];
-    sushi_fft::fft_wave_mfma_front<1>(yl, v, tid, tw, mb);
-    float m2 = 0.f;
-#pragma unroll
-    for (int r = 0; r < sushi_fft::PER; ++r) m2 = fmaxf(m2, __builtin_fmaf(v[r].x, v[r].x, v[r].y * v[r].y));
-    const float wm = wave_max_f32(m2), qw = wave_sum_f32(q2);
-    if (lane == 0) { red_b[wave] = sqrtf(wm) * 1.000002f; red_q[wave] = qw; }
-    // lower bound of the window energies: the stretches of COARSE_G positions that hold a valid position of the search
-    constexpr int NSB = 2 * FH / COARSE_G;
-    static_assert(NSB <= 128 && (FFT_STEP * FFT_SEG) % COARSE_G == 0, "two waves look the stretches up");
-    if (wave < 2) {
-        const int64_t plo = sd.win_start - qbase, phi = (int64_t)sd.n_pos + (sd.win_start - qbase);   // valid: plo <= pos < phi
-        float wl = __builtin_inff();
-        const int64_t p0 = (int64_t)tid * COARSE_G;
-        if (tid < NSB && p0 + COARSE_G > plo && p0 < phi) {
-            const int64_t j = qbase / COARSE_G + tid;
-            int64_t je = j + M / COARSE_G, js = j + 1;
-            je = je < a.nc - 1 ? je : a.nc - 1;
-            js = js < a.nc - 1 ? js : a.nc - 1;
-            const double e = je > js ? a.coarse[je] - a.coarse[js] : 0.0;
-            wl = fmaxf((float)e * 0.9999995f, 0.f);
-        }
-        const float wmin = wave_min_f32(wl);
-        if (lane == 0) red_w[wave] = wmin;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float B = 0.f, qmax = 0.f;
-#pragma unroll
-        for (int w = 0; w < FT / 64; ++w) { B += red_b[w]; qmax = fmaxf(qmax, red_q[w]); }
-        const float wlb = fminf(red_w[0], red_w[1]);
+        const double zn_c = sqrt(fmax(e2, 0.0)) * 1.0000005, zn = sqrt(fmax(u1 - u0, 0.0)) * 1.0000005;
         const int mac_passes = (n_seg + MAC_SMAX_LONG - 1) / MAC_SMAX_LONG;
         const double sigma_y = sqrt((double)((float)(FT / 64) * qmax) * (7.9472862e-8 * (double)(2 + mac_passes)) + (double)FN * 1.2e-15) *
                                (double)tc.inv_scale;
-        // what the exact centred cross term of any position of this pair can reach: the bound of the transform's outputs (its
-        // own float32 rounding included in the factor), the FFT stage's error, the packed halves' modelled error
-        const double ymax = (double)B * (double)tc.inv_scale * 1.00002 + err_y + (double)Y_KQ * sigma_y;
-        const double a0 = tU2 - 2.0 * ymax;
+        // what the exact cross term of any position of this pair can reach: the bound of the transform's outputs (its own
+        // float32 rounding included in the factor), the FFT stage's error, the packed halves' modelled error
+        const double tn = CC ? (tc.inv_tnorm_c > 0.f ? 1.0 / (double)tc.inv_tnorm_c : 0.0) : (double)tc.tnorm;
+        const double ymax = (double)B * (double)tc.inv_scale * 1.00002 + 5.9604645e-8 * (double)FFT_KE * (CC ? fmax(zn, zn_c) : zn_c) * tn +
+                            (double)Y_KQ * sigma_y;
         float slb = -__builtin_inff();
-        if (wlb > 0.f && wlb < __builtin_inff() && a0 < (double)wlb && tc.tU > 0.0)
-            slb = (float)((a0 + (double)wlb) / (sqrt((double)wlb) * (double)tc.tnorm) * 0.999999);
+        if (CC) {
+            if (wlb > 0.f && wlb < __builtin_inff() && !tc.flat && tn > 0.0)
+                slb = (float)(1.0 - ymax / (tn * sqrt((double)wlb)) * 1.000001);
+        } else {
+            const double a0 = (tc.tU - 2.0 * (double)tc.c_sum_t) - 2.0 * ymax;
+            if (wlb > 0.f && wlb < __builtin_inff() && a0 < (double)wlb && tc.tU > 0.0)
+                slb = (float)((a0 + (double)wlb) / (sqrt((double)wlb) * (double)tc.tnorm) * 0.999999);
+        }
         a.slb[pr] = slb;
     }
 }
@@ -1339,7 +1413,7 @@ inline int64_t cand_capacity(int64_t pairs) {
 }
 
 // bytes of workspace for one sub-batch of `pairs` block pairs, `segs` pattern segments and `searches` searches
-struct WsLayout { size_t tspec, y, cand, pair_lb, pairmap, tconst, tiles, candbuf, dummy, slb, plist, slist, scount, total; };
+struct WsLayout { size_t tspec, y, cand, pair_lb, pairmap, tconst, tiles, candbuf, dummy, slb, acc, plist, slist, scount, total; };
 inline WsLayout ws_layout(int64_t pairs, int64_t segs, int64_t searches) {
     WsLayout w;
     size_t o = 0;
@@ -1353,6 +1427,7 @@ inline WsLayout ws_layout(int64_t pairs, int64_t segs, int64_t searches) {
     w.candbuf = o; o += align_up((size_t)cand_capacity(pairs) * sizeof(int32_t), 256);
     w.dummy = o; o += align_up((size_t)MAC_DUMMY_LINES * MAC_THREADS * sizeof(uint4), 256);
     w.slb = o; o += align_up((size_t)pairs * sizeof(float), 256);
+    w.acc = o; o += align_up((size_t)pairs * 2 * sizeof(float), 256);
     w.plist = o; o += align_up((size_t)searches * sizeof(int), 256);
     w.slist = o; o += align_up((size_t)pairs * sizeof(int), 256);
     w.scount = o; o += 256;
@@ -1781,7 +1856,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         TspecArgs ta;
         ta.src_raw = src->raw; ta.searches = searches_dev + sbt.a0; ta.n_sub = n_sub; ta.sub_first_seg = sbt.first_seg;
         ta.tspec = tspec; ta.sub_first_pair = sbt.first_pair; ta.pairmap = pairmap; ta.tconst = tconst;
-        ta.src_s1 = src->s1; ta.src_s2 = src->s2; ta.centre = r.centre; ta.dst_stats = dst->stats;
+        ta.src_s1 = src->s1; ta.src_s2 = src->s2; ta.centre = r.centre; ta.dst_stats = dst->stats; ta.method = b->method;
         if (src->dtype == SUSHI_HIP_F32) hipLaunchKernelGGL(tspec_kernel<float>, dim3((unsigned)sbt.segs), dim3(FT), 0, st, ta);
         else hipLaunchKernelGGL(tspec_kernel<uint8_t>, dim3((unsigned)sbt.segs), dim3(FT), 0, st, ta);
         if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
@@ -1820,13 +1895,16 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         ia.usrel = dst->usrel; ia.sbase = dst->base + (dst->blocks + 1);
         ia.flags = flags; ia.flag_list = flag_list; ia.sub_flagged = sub_flagged; ia.tiles = tiles; ia.candbuf = candbuf;
         ia.cand_cap = (int)cand_capacity(sbt.pairs); ia.counters = counters;
-        if (b->method == SUSHI_HIP_METHOD_CCOEFF_NORMED) {
-            hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3((unsigned)sbt.pairs), dim3(FT), 0, st, ia);
-            if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-        } else {
-            // TM_SQDIFF_NORMED: a lower bound of every pair's scores first (three of the transform's four passes, no scoring);
-            // then the most promising pair of every search, which leaves the search's threshold; then whatever the bound
-            // could not exclude (header of bound_kernel)
+        {
+            // A lower bound of every pair's scores first (three of the transform's four passes, no scoring); then the most
+            // promising pair of every search, which leaves the search's threshold; then whatever the bound could not exclude
+            // (header of bound_kernel)
+            const bool ccm = b->method == SUSHI_HIP_METHOD_CCOEFF_NORMED;
+            auto launch_ifft = [&](const IfftArgs& x, unsigned grid) {
+                if (ccm) hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3(grid), dim3(FT), 0, st, x);
+                else hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3(grid), dim3(FT), 0, st, x);
+                return launch_ok();
+            };
             BoundArgs ba;
             memset(&ba, 0, sizeof(ba));
             ba.y = (const uint2*)y; ba.dst_stats = dst->stats; ba.searches = searches_dev + sbt.a0; ba.sub_first_pair = sbt.first_pair;
@@ -1835,21 +1913,29 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             ba.slb = (float*)(wsp + wl.slb); ba.n_sub = n_sub; ba.n_pairs = (int)sbt.pairs; ba.plist = (int*)(wsp + wl.plist);
             ba.slist = (int*)(wsp + wl.slist); ba.scount = (int*)(wsp + wl.scount); ba.order = order + sbt.first_pair;
             ba.gkeys = gkeys; ba.pair_lb = pair_lb; ba.counters = counters;
-            hipLaunchKernelGGL(bound_kernel, dim3((unsigned)sbt.pairs), dim3(FT), 0, st, ba);
-            if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            ba.acc = (float*)(wsp + wl.acc);
+            if (hipMemsetAsync(ba.acc, 0, (size_t)sbt.pairs * 2 * sizeof(float), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+            {
+                // persistent waves: three workgroups of four per CU (the kernel's register budget), fewer for a small batch
+                const int64_t want = (sbt.pairs * 16 + BOUND_THREADS / 64 - 1) / (BOUND_THREADS / 64);
+                const unsigned grid = (unsigned)std::min<int64_t>(want, 256 * 3);
+                hipLaunchKernelGGL(bound_kernel, dim3(grid), dim3(BOUND_THREADS), 0, st, ba);
+                if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+                if (ccm) hipLaunchKernelGGL(slb_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3((unsigned)((sbt.pairs + 3) / 4)), dim3(256), 0, st, ba);
+                else hipLaunchKernelGGL(slb_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3((unsigned)((sbt.pairs + 3) / 4)), dim3(256), 0, st, ba);
+                if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            }
             prof_end(pc, t0, SUSHI_HIP_STAGE_BOUND, st);
             t0 = prof_begin(pc, st);
             hipLaunchKernelGGL(pilot_kernel, dim3((unsigned)n_sub), dim3(64), 0, st, ba);
             if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             IfftArgs ip = ia;
             ip.order = ba.plist; ip.count = nullptr;
-            hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3((unsigned)n_sub), dim3(FT), 0, st, ip);
-            if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            if (launch_ifft(ip, (unsigned)n_sub) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             hipLaunchKernelGGL(survivor_kernel, dim3((unsigned)((sbt.pairs + 255) / 256)), dim3(256), 0, st, ba);
             if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             ip.order = ba.slist; ip.count = ba.scount;
-            hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3((unsigned)sbt.pairs), dim3(FT), 0, st, ip);
-            if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            if (launch_ifft(ip, (unsigned)sbt.pairs) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
         }
         prof_end(pc, t0, SUSHI_HIP_STAGE_IFFT, st);
 

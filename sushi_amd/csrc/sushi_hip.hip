@@ -338,12 +338,20 @@ void exact_tiles_kernel(TileParams a) {
     const int n_tiles = a.counters->n_tiles;
     if (n_tiles == 0) return;
     const int tid = threadIdx.x;
-    for (int v = blockIdx.x; v < n_tiles; v += gridDim.x) {
+    // A few tiles only (a couple of flagged searches) are a latency problem, not a throughput one: a dense tile is then cut
+    // into XQ workgroups of one position per thread -- the chain of dependent multiply-adds a thread walks is a quarter as long.
+    // Each position's sum is the same chain either way.
+    const int split = n_tiles * 2 <= (int)gridDim.x ? XQ : 1;
+    for (int item = blockIdx.x; item < n_tiles * split; item += gridDim.x) {
+        const int v = item / split, sub = item - v * split;
         const TileDesc td = a.tiles[v];
         const SearchDesc sd = a.searches[td.search];
         const int M = sd.tmpl_len;
-        const int p0 = td.p0;                                           // may be negative: tiles sit on the absolute grid
         const bool dense = td.cnt < 0;
+        if (!dense && sub > 0) continue;                                // a sparse tile is one workgroup's work (uniform)
+        const bool quarter = dense && split > 1;
+        const int p0 = td.p0 + (quarter ? sub * 256 : 0);               // may be negative: tiles sit on the absolute grid
+        const int span = quarter ? 256 : XT;                            // positions this workgroup covers
         const T* __restrict__ Tp = (const T*)a.r.src_raw + sd.tmpl_off;
         const T* __restrict__ Ip = (const T*)a.r.dst_raw + (sd.win_start + p0);
         const int64_t room = a.r.dst_len - (sd.win_start + p0);         // samples of the stream from Ip on
@@ -354,9 +362,22 @@ void exact_tiles_kernel(TileParams a) {
             const int mc = min(XM, M - m0);
             __syncthreads();                                            // previous chunk's (or tile's) reads are done
             for (int e = tid; e < XM; e += 256) lt[e] = e < mc ? (float)Tp[m0 + e] : 0.f;      // zero padded: whole steps of 4
-            for (int e = tid; e < XT + XM; e += 256) li[e] = (int64_t)m0 + e < room ? (float)Ip[m0 + e] : 0.f;
+            for (int e = tid; e < span + XM; e += 256) li[e] = (int64_t)m0 + e < room ? (float)Ip[m0 + e] : 0.f;
             __syncthreads();
-            if (dense) {
+            if (quarter) {
+                const float4* __restrict__ lt4 = reinterpret_cast<const float4*>(lt);
+                const float* __restrict__ wv = li + tid;
+                double acc = 0.0;
+                for (int k = 0; k < (mc + 3) / 4; ++k) {
+                    const float4 t4 = lt4[k];
+                    const float w0 = wv[4 * k], w1 = wv[4 * k + 1], w2 = wv[4 * k + 2], w3 = wv[4 * k + 3];
+                    acc = __builtin_fma((double)t4.x, (double)w0, acc);    // pattern samples in order (padding adds exact zeros)
+                    acc = __builtin_fma((double)t4.y, (double)w1, acc);
+                    acc = __builtin_fma((double)t4.z, (double)w2, acc);
+                    acc = __builtin_fma((double)t4.w, (double)w3, acc);
+                }
+                tot[0] += acc;
+            } else if (dense) {
                 const float4* __restrict__ li4 = reinterpret_cast<const float4*>(li) + tid;   // li[4 tid + 4 k ..]
                 const float4* __restrict__ lt4 = reinterpret_cast<const float4*>(lt);
                 double acc[XQ] = {0.0, 0.0, 0.0, 0.0};
@@ -392,7 +413,10 @@ void exact_tiles_kernel(TileParams a) {
                           : make_key(score_exact(corr_u, ts, w2, (int64_t)p, M), (unsigned)p);
         };
         unsigned long long best = NO_KEY;
-        if (dense) {
+        if (quarter) {
+            const int p = p0 + tid;
+            if (p >= 0 && p < sd.n_pos) best = key_at(tot[0], p);
+        } else if (dense) {
 #pragma unroll
             for (int q = 0; q < XQ; ++q) {
                 const int p = p0 + XQ * tid + q;
