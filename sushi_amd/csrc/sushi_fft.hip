@@ -555,6 +555,8 @@ struct IfftArgs {
     const int* flags;                 // [all searches] 1 = list the candidates, 2 = every position
     const int* flag_list;             // flagged searches of this sub-batch (global indices)
     const int* sub_flagged;           // how many
+    const int* citems;                // the (flagged search, pair) items refine_kernel listed: pair indices inside the sub-batch
+    const int* n_citems;              // [1] how many
     TileDesc* tiles;
     int32_t* candbuf;
     int cand_cap;
@@ -1292,34 +1294,38 @@ void survivor_kernel(BoundArgs a) {
 
 // Collection pass over the flagged searches of a sub-batch: the same transforms and scores again (bit for bit), now
 // against the search's final threshold; every candidate goes to its tile's list, tiles with many candidates (or
-// when the buffer is full) are marked dense.  Grid: x strides over a search's pairs, y over the flagged searches.
+// when the buffer is full) are marked dense.  A fixed grid strides over the (search, pair) items refine_kernel listed.
 constexpr int SPARSE_MAX = 256;            // candidates per tile up to which they are listed; beyond: every position
+constexpr int COLLECT_GRID = 1024;         // collect_kernel's workgroups: two per CU, twice over
 
 template <int METHOD>
 __global__ __launch_bounds__(FT, 8)
 void collect_kernel(IfftArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     __shared__ int tcnt[TILES_PER_PAIR], toff[TILES_PER_PAIR], tfill[TILES_PER_PAIR];
-    const int n_flagged = *a.sub_flagged;
-    if (n_flagged == 0) return;
-    const int tid = threadIdx.x;
-    const sushi_fft::WTwiddles tw = sushi_fft::load_wtwiddles<1>(tid, twiddles());
-    const sushi_fft::MfmaB mb = dft16_operands(tid);
-    const int lane = tid & 63;
-    for (int f = blockIdx.y; f < n_flagged; f += gridDim.y) {
-        const int s_idx = a.flag_list[f];                                  // global search index
-        const int k = s_idx - a.first_search;
-        const SearchDesc sd = a.searches[k];
-        const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
-        const TemplConsts tc = a.tconst[k];
-        const bool everything = a.flags[s_idx] == 2;
-        // smallest (score + bound) of the search; none (TM_CCOEFF_NORMED: every window uncertain): everything is a candidate
-        const float U = a.gkeys[s_idx] == NO_KEY ? 4.0f : key_score(a.gkeys[s_idx]);
-        for (int i = blockIdx.x; i < lay.n_pairs; i += gridDim.x) {
-            const int pr = sd.first_pair - a.sub_first_pair + i;
-            // ifft_kernel left the smallest lower bound of this pair's positions: above the search's threshold, the pair holds no
-            // candidate and its transform need not be redone (workgroup-uniform)
-            if (!everything && !(a.pair_lb[pr] <= U)) continue;
+    const int n_items = *a.n_citems;
+    if (n_items == 0) return;
+    // refine_kernel listed, for every search it flagged, the pairs that can hold a candidate (all pairs for a search that goes
+    // to every position): a fixed grid strides over that list -- every workgroup has work while there is any
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        {
+            // everything an iteration needs is loaded inside it, off a thread index the compiler cannot see through: left to
+            // hoist the transform's per-thread constants and addresses out of the loop it spilled hundreds of bytes of them
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const sushi_fft::WTwiddles tw = sushi_fft::load_wtwiddles<1>(tid, twiddles());
+            const sushi_fft::MfmaB mb = dft16_operands(tid);
+            const int lane = tid & 63;
+            const int pr = __builtin_amdgcn_readfirstlane(a.citems[it]);
+            const int k = __builtin_amdgcn_readfirstlane(a.pairmap[pr]);
+            const int s_idx = a.first_search + k;                              // global search index
+            const SearchDesc sd = a.searches[k];
+            const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
+            const TemplConsts tc = a.tconst[k];
+            const bool everything = a.flags[s_idx] == 2;
+            // smallest (score + bound) of the search; none (TM_CCOEFF_NORMED: every window uncertain): everything is a candidate
+            const float U = a.gkeys[s_idx] == NO_KEY ? 4.0f : key_score(a.gkeys[s_idx]);
+            const int i = a.sub_first_pair + pr - sd.first_pair;
             const int64_t qbase = (lay.pair0 + i) * (int64_t)FFT_STEP * FFT_SEG;
             const int64_t rel0 = qbase - sd.win_start;                     // position (relative to the window) of pos 0
             __syncthreads();                                               // previous item's shared state is consumed
@@ -1355,33 +1361,42 @@ void collect_kernel(IfftArgs a) {
                 }
             }
             __syncthreads();
-            if (tid < TILES_PER_PAIR && tcnt[tid] > 0) {
-                const int cnt = tcnt[tid];
-                int off = -1;
-                if (cnt <= SPARSE_MAX) {
-                    // take cnt entries of the candidate buffer, or none: the counter never passes cand_cap (an
-                    // unconditional add would keep growing after the buffer is full and could wrap over a large
-                    // all-flagged sub-batch)
-                    int seen = a.counters->n_cand;
-                    while (seen + cnt <= a.cand_cap) {
-                        const int prev = atomicCAS(&a.counters->n_cand, seen, seen + cnt);
-                        if (prev == seen) { off = seen; break; }
-                        seen = prev;
-                    }                                                       // buffer full: evaluate the whole tile
+            if (tid == 0) {
+                // One thread hands out this pair's tiles: ONE addition to each of the run's counters per workgroup (a tile at a time,
+                // from 24 threads of every workgroup, the same-address atomics -- and a compare-and-swap loop among them -- were
+                // most of this kernel's time).  The candidate buffer's counter never runs far past its capacity: a workgroup that
+                // sees it full does not add to it (its tiles are evaluated at every position instead).
+                int total = 0, nt = 0, n_sparse = 0;
+                for (int t = 0; t < TILES_PER_PAIR; ++t) {
+                    const int cnt = tcnt[t];
+                    if (cnt > 0) { ++nt; if (cnt <= SPARSE_MAX) { total += cnt; ++n_sparse; } }
                 }
-                toff[tid] = off;
-                const int slot = atomicAdd(&a.counters->n_tiles, 1);        // capacity: every tile of every pair
-                TileDesc td;
-                td.search = s_idx;
-                td.p0 = (int)(rel0 + (int64_t)tid * TILE);
-                td.off = off;
-                td.cnt = off >= 0 ? cnt : -1;
-                a.tiles[slot] = td;
-                if (off >= 0) {
-                    atomicAdd(&a.counters->tiles_sparse, 1ull);
-                    atomicAdd(&a.counters->candidates, (unsigned long long)cnt);
-                } else {
-                    atomicAdd(&a.counters->tiles_dense, 1ull);
+                if (nt > 0) {
+                    int base = -1;
+                    if (total > 0 && *(volatile int*)&a.counters->n_cand + total <= a.cand_cap) {
+                        const int o = atomicAdd(&a.counters->n_cand, total);
+                        if (o + total <= a.cand_cap) base = o;
+                    }
+                    int slot = atomicAdd(&a.counters->n_tiles, nt);             // capacity: every tile of every pair
+                    for (int t = 0; t < TILES_PER_PAIR; ++t) {
+                        const int cnt = tcnt[t];
+                        if (cnt <= 0) continue;
+                        int off = -1;
+                        if (cnt <= SPARSE_MAX && base >= 0) { off = base; base += cnt; }
+                        toff[t] = off;
+                        TileDesc td;
+                        td.search = s_idx;
+                        td.p0 = (int)(rel0 + (int64_t)t * TILE);
+                        td.off = off;
+                        td.cnt = off >= 0 ? cnt : -1;
+                        a.tiles[slot++] = td;
+                    }
+                    const int listed = base >= 0 || total == 0 ? n_sparse : 0;  // (all of the pair's sparse tiles are listed, or none)
+                    if (listed > 0) {
+                        atomicAdd(&a.counters->tiles_sparse, (unsigned long long)listed);
+                        atomicAdd(&a.counters->candidates, (unsigned long long)total);
+                    }
+                    if (nt - listed > 0) atomicAdd(&a.counters->tiles_dense, (unsigned long long)(nt - listed));
                 }
             }
             __syncthreads();
@@ -1413,7 +1428,7 @@ inline int64_t cand_capacity(int64_t pairs) {
 }
 
 // bytes of workspace for one sub-batch of `pairs` block pairs, `segs` pattern segments and `searches` searches
-struct WsLayout { size_t tspec, y, cand, pair_lb, pairmap, tconst, tiles, candbuf, dummy, slb, acc, plist, slist, scount, total; };
+struct WsLayout { size_t tspec, y, cand, pair_lb, pairmap, tconst, tiles, candbuf, dummy, slb, acc, plist, slist, scount, citems, total; };
 inline WsLayout ws_layout(int64_t pairs, int64_t segs, int64_t searches) {
     WsLayout w;
     size_t o = 0;
@@ -1430,7 +1445,8 @@ inline WsLayout ws_layout(int64_t pairs, int64_t segs, int64_t searches) {
     w.acc = o; o += align_up((size_t)pairs * 2 * sizeof(float), 256);
     w.plist = o; o += align_up((size_t)searches * sizeof(int), 256);
     w.slist = o; o += align_up((size_t)pairs * sizeof(int), 256);
-    w.scount = o; o += 256;
+    w.scount = o; o += 256;                                                      // [0] survivors, [1] collect items
+    w.citems = o; o += align_up((size_t)pairs * sizeof(int), 256);
     w.total = o;
     return w;
 }
@@ -1944,6 +1960,8 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         rp.r = r; rp.searches = searches_dev; rp.first_search = sbt.a0; rp.n_sub = n_sub; rp.sub_first_pair = sbt.first_pair;
         rp.cand = cand; rp.pair_lb = pair_lb; rp.gkeys = gkeys; rp.keys = keys; rp.flags = flags; rp.flag_list = flag_list;
         rp.sub_flagged = sub_flagged; rp.counters = counters; rp.delta = (float)delta; rp.method = b->method;
+        rp.citems = (int*)(wsp + wl.citems); rp.n_citems = (int*)(wsp + wl.scount) + 1;
+        ia.citems = rp.citems; ia.n_citems = rp.n_citems;
         int rc = launch_refine(rp, st);
         if (rc != SUSHI_HIP_OK) return rc;
         prof_end(pc, t0, SUSHI_HIP_STAGE_REFINE, st);
@@ -1952,9 +1970,9 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         // (both kernels leave after one load when nothing is flagged)
         t0 = prof_begin(pc, st);
         if (b->method == SUSHI_HIP_METHOD_CCOEFF_NORMED)
-            hipLaunchKernelGGL(collect_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3(32, (unsigned)std::min(n_sub, 128)), dim3(FT), 0, st, ia);
+            hipLaunchKernelGGL(collect_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3(COLLECT_GRID), dim3(FT), 0, st, ia);
         else
-            hipLaunchKernelGGL(collect_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3(32, (unsigned)std::min(n_sub, 128)), dim3(FT), 0, st, ia);
+            hipLaunchKernelGGL(collect_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3(COLLECT_GRID), dim3(FT), 0, st, ia);
         if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
         TileParams tp;
         tp.r = r; tp.searches = searches_dev; tp.tiles = tiles; tp.cand = candbuf; tp.keys = keys; tp.counters = counters;

@@ -332,8 +332,9 @@ template <typename T>
 __global__ __launch_bounds__(256)
 void exact_tiles_kernel(TileParams a) {
     constexpr int XQ = XT / 256;
-    __shared__ __attribute__((aligned(16))) float lt[XM];
-    __shared__ __attribute__((aligned(16))) float li[XT + XM];
+    // chunks are staged as float64: the conversions (quarter rate) happen once per staged sample, not once per multiply-add
+    __shared__ __attribute__((aligned(16))) double lt[XM];
+    __shared__ __attribute__((aligned(16))) double li[XT + XM];
     __shared__ unsigned long long red[4];
     const int n_tiles = a.counters->n_tiles;
     if (n_tiles == 0) return;
@@ -361,46 +362,46 @@ void exact_tiles_kernel(TileParams a) {
         for (int m0 = 0; m0 < M; m0 += XM) {
             const int mc = min(XM, M - m0);
             __syncthreads();                                            // previous chunk's (or tile's) reads are done
-            for (int e = tid; e < XM; e += 256) lt[e] = e < mc ? (float)Tp[m0 + e] : 0.f;      // zero padded: whole steps of 4
-            for (int e = tid; e < span + XM; e += 256) li[e] = (int64_t)m0 + e < room ? (float)Ip[m0 + e] : 0.f;
+            for (int e = tid; e < XM; e += 256) lt[e] = e < mc ? (double)Tp[m0 + e] : 0.0;      // zero padded: whole steps of 4
+            for (int e = tid; e < span + XM; e += 256) li[e] = (int64_t)m0 + e < room ? (double)Ip[m0 + e] : 0.0;
             __syncthreads();
+            typedef double d2 __attribute__((ext_vector_type(2)));
             if (quarter) {
-                const float4* __restrict__ lt4 = reinterpret_cast<const float4*>(lt);
-                const float* __restrict__ wv = li + tid;
+                const d2* __restrict__ lt2 = reinterpret_cast<const d2*>(lt);
+                const double* __restrict__ wv = li + tid;
                 double acc = 0.0;
                 for (int k = 0; k < (mc + 3) / 4; ++k) {
-                    const float4 t4 = lt4[k];
-                    const float w0 = wv[4 * k], w1 = wv[4 * k + 1], w2 = wv[4 * k + 2], w3 = wv[4 * k + 3];
-                    acc = __builtin_fma((double)t4.x, (double)w0, acc);    // pattern samples in order (padding adds exact zeros)
-                    acc = __builtin_fma((double)t4.y, (double)w1, acc);
-                    acc = __builtin_fma((double)t4.z, (double)w2, acc);
-                    acc = __builtin_fma((double)t4.w, (double)w3, acc);
+                    const d2 ta = lt2[2 * k], tb = lt2[2 * k + 1];
+                    const double w0 = wv[4 * k], w1 = wv[4 * k + 1], w2 = wv[4 * k + 2], w3 = wv[4 * k + 3];
+                    acc = __builtin_fma(ta.x, w0, acc);                    // pattern samples in order (padding adds exact zeros)
+                    acc = __builtin_fma(ta.y, w1, acc);
+                    acc = __builtin_fma(tb.x, w2, acc);
+                    acc = __builtin_fma(tb.y, w3, acc);
                 }
                 tot[0] += acc;
             } else if (dense) {
-                const float4* __restrict__ li4 = reinterpret_cast<const float4*>(li) + tid;   // li[4 tid + 4 k ..]
-                const float4* __restrict__ lt4 = reinterpret_cast<const float4*>(lt);
+                const d2* __restrict__ li2 = reinterpret_cast<const d2*>(li) + 2 * tid;       // li[4 tid + 4 k ..]
+                const d2* __restrict__ lt2 = reinterpret_cast<const d2*>(lt);
                 double acc[XQ] = {0.0, 0.0, 0.0, 0.0};
-                float4 lo = li4[0];
+                d2 lo0 = li2[0], lo1 = li2[1];
                 for (int k = 0; k < (mc + 3) / 4; ++k) {
-                    const float4 hi = li4[k + 1];
-                    const float4 t4 = lt4[k];
-                    const double w[8] = {(double)lo.x, (double)lo.y, (double)lo.z, (double)lo.w,
-                                         (double)hi.x, (double)hi.y, (double)hi.z, (double)hi.w};
-                    const double t[4] = {(double)t4.x, (double)t4.y, (double)t4.z, (double)t4.w};
+                    const d2 hi0 = li2[2 * k + 2], hi1 = li2[2 * k + 3];
+                    const d2 ta = lt2[2 * k], tb = lt2[2 * k + 1];
+                    const double w[8] = {lo0.x, lo0.y, lo1.x, lo1.y, hi0.x, hi0.y, hi1.x, hi1.y};
+                    const double t[4] = {ta.x, ta.y, tb.x, tb.y};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {                          // pattern samples in order (padding adds exact zeros)
 #pragma unroll
                         for (int q = 0; q < XQ; ++q) acc[q] = __builtin_fma(t[j], w[q + j], acc[q]);
                     }
-                    lo = hi;
+                    lo0 = hi0; lo1 = hi1;
                 }
 #pragma unroll
                 for (int q = 0; q < XQ; ++q) tot[q] += acc[q];
             } else if (mine >= 0) {
-                const float* __restrict__ wv = li + mine;
+                const double* __restrict__ wv = li + mine;
                 double acc = 0.0;
-                for (int m = 0; m < mc; ++m) acc = __builtin_fma((double)lt[m], (double)wv[m], acc);
+                for (int m = 0; m < mc; ++m) acc = __builtin_fma(lt[m], wv[m], acc);
                 tot[0] += acc;
             }
         }
@@ -549,7 +550,7 @@ __device__ __forceinline__ void refine_body(const RefineParams& a, const int s_i
     __syncthreads();
 }
 
-__global__ __launch_bounds__(REFINE_THREADS)
+__global__ __launch_bounds__(REFINE_THREADS, 4)
 void refine_kernel(RefineParams a) {
     __shared__ unsigned long long list[RENT], rkey[RENT];
     __shared__ int lpair[RENT];
@@ -632,6 +633,12 @@ void refine_kernel(RefineParams a) {
         __syncthreads();
         if (tid == 0 && n_all > n) atomicAdd(&a.counters->audited, (unsigned long long)(n_all - n));
     }
+    if (ovf || violated) {
+        // this search goes to the collection pass: list its pairs that can hold a candidate (every pair when every position is
+        // to be evaluated) -- what collect_kernel's workgroups stride over
+        for (int i = tid; i < lay.n_pairs; i += REFINE_THREADS)
+            if (violated || plb[i] <= U) a.citems[atomicAdd(a.n_citems, 1)] = (sd.first_pair - a.sub_first_pair) + i;
+    }
     if (tid == 0) {
         // the run's maxima: one global atomic per search only where it raises the value -- every workgroup hitting the same two
         // words with an atomic each was most of this kernel's time (same-address atomics serialise in the L2)
@@ -656,8 +663,9 @@ void refine_kernel(RefineParams a) {
 }
 
 // first launch of a sub-batch's exact stages: nothing flagged yet, no tile listed yet
-__global__ void reset_sub_kernel(int* sub_flagged, RunCounters* counters) {
+__global__ void reset_sub_kernel(int* sub_flagged, int* n_citems, RunCounters* counters) {
     *sub_flagged = 0;
+    *n_citems = 0;
     counters->n_tiles = 0;
     counters->n_cand = 0;
 }
@@ -922,7 +930,7 @@ int launch_direct(const StreamRefs& r, const SearchDesc* searches_dev, int n_sea
 }
 
 int launch_refine(const RefineParams& p, hipStream_t st) {
-    hipLaunchKernelGGL(reset_sub_kernel, dim3(1), dim3(1), 0, st, p.sub_flagged, p.counters);
+    hipLaunchKernelGGL(reset_sub_kernel, dim3(1), dim3(1), 0, st, p.sub_flagged, p.n_citems, p.counters);
     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
     hipLaunchKernelGGL(refine_kernel, dim3(p.n_sub), dim3(REFINE_THREADS), 0, st, p);
     return launch_ok();

@@ -93,6 +93,8 @@ struct RefineParams {
     int* flags;                       // [all searches]
     int* flag_list;                   // [n_sub] flagged searches of this sub-batch (global indices)
     int* sub_flagged;                 // [1] how many
+    int* citems;                      // [pairs of the sub-batch] out: the pairs of flagged searches collect_kernel has to look at
+    int* n_citems;                    // [1] how many
     RunCounters* counters;
     float delta;
     int method;                       // SUSHI_HIP_METHOD_*
