@@ -106,6 +106,8 @@ SUSHI_HIP_API int sushi_hip_stream_add_spectra(SushiHipStream* stream, void* mem
 #define SUSHI_HIP_VIEW_SPECTRA 5
 #define SUSHI_HIP_VIEW_USREL 6    /* float32[n+1][2]: (urel[e], srel[e]), s1[e] = base1[e / B] + srel[e] (TM_CCOEFF_NORMED's window sums on the FFT path) */
 #define SUSHI_HIP_VIEW_BASE1 7    /* float64[nb+1] */
+#define SUSHI_HIP_VIEW_COARSE 8   /* float64[2][n / 256 + 2]: s2, then s1, at every 256th sample (entries past the end: the totals) --
+                                    what the FFT path's lower bound of a block pair's window energies reads */
 SUSHI_HIP_API int sushi_hip_stream_view(const SushiHipStream* stream, int which, const void** ptr_dev, size_t* bytes);
 SUSHI_HIP_API void sushi_hip_stream_destroy(SushiHipStream* stream);
 

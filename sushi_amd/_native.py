@@ -19,7 +19,7 @@ U8, F32 = 0, 1
 PATH_FFT, PATH_DIRECT = 0, 1
 METHOD_SQDIFF_NORMED, METHOD_CCOEFF_NORMED = 0, 1       # cv2.TM_SQDIFF_NORMED + argmin (wav.py:185-186) | cv2.TM_CCOEFF_NORMED + argmax
 METHODS = {"sqdiff_normed": METHOD_SQDIFF_NORMED, "ccoeff_normed": METHOD_CCOEFF_NORMED}
-VIEW_XC, VIEW_S1, VIEW_S2, VIEW_UREL, VIEW_BASE, VIEW_SPECTRA, VIEW_USREL, VIEW_BASE1 = range(8)
+VIEW_XC, VIEW_S1, VIEW_S2, VIEW_UREL, VIEW_BASE, VIEW_SPECTRA, VIEW_USREL, VIEW_BASE1, VIEW_COARSE = range(9)
 
 ABI_VERSION = 9
 NSTAGES = 6

@@ -1075,6 +1075,7 @@ int sushi_hip_stream_view(const SushiHipStream* s, int which, const void** ptr_d
         case SUSHI_HIP_VIEW_SPECTRA: *ptr_dev = s->spec; *bytes = s->spec_bytes; break;
         case SUSHI_HIP_VIEW_USREL: *ptr_dev = s->usrel; *bytes = (size_t)(s->n + 1) * 2 * sizeof(float); break;
         case SUSHI_HIP_VIEW_BASE1: *ptr_dev = s->base + (s->blocks + 1); *bytes = (size_t)(s->blocks + 1) * sizeof(double); break;
+        case SUSHI_HIP_VIEW_COARSE: *ptr_dev = s->coarse; *bytes = (size_t)2 * (size_t)s->nc * sizeof(double); break;
         default: return SUSHI_HIP_EINVAL;
     }
     return SUSHI_HIP_OK;

@@ -1,0 +1,141 @@
+"""The FFT path's pair exclusion (sushi_fft.hip: bound_kernel / slb_kernel / pilot_kernel / survivor_kernel): a block pair whose
+LOWER bound of all its scores is above what the search has already found is never transformed.  What must hold:
+  * results are the oracle's whatever is excluded (every other GPU parity test runs through the same machinery; the cases here
+    are the ones built to break it: the match on a pair boundary, the same material twice in different pairs -- an exact tie
+    whose FIRST occurrence must win --, a match so poor that nothing may be excluded, patterns too short for the bound);
+  * on stream-like data with a real match almost every pair IS excluded (the point of it);
+  * the coarse prefix table the window-energy bound reads is what it says it is."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PAIR = 6 * 4096                 # positions per block pair on the absolute grid
+
+
+def _stream(n, seed, lowpass=8):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(n + lowpass)
+    c = np.cumsum(x)
+    y = (c[lowpass:] - c[:-lowpass]) / lowpass
+    y = y / np.abs(y).max() * 0.35 + 0.5
+    return y.astype(np.float32)
+
+
+def _run(dst, src, offs, lens, wst, npos, method="sqdiff_normed"):
+    from sushi_amd.device import DeviceStream, SearchBatch
+    b = SearchBatch(DeviceStream(dst), DeviceStream(src), offs, lens, wst, npos, path="fft", method=method)
+    b.run()
+    idx, score = b.results()
+    return idx, score, b
+
+
+def _oracle(oracle, dst, src, off, m, ws, p, method="sqdiff_normed"):
+    row = oracle.match_template(dst[ws:ws + p + m - 1], src[off:off + m], method=method)[0]
+    k = int(row.argmin() if method == "sqdiff_normed" else row.argmax())
+    return k, float(row[k]), row
+
+
+@pytest.mark.parametrize("method", ["sqdiff_normed", "ccoeff_normed"])
+def test_almost_every_pair_is_excluded_and_the_results_are_the_oracles(oracle, method):
+    n = 40 * PAIR
+    dst = _stream(n, 1)
+    rng = np.random.default_rng(2)
+    src = (dst + rng.standard_normal(n).astype(np.float32) * 0.02).clip(0, 1).astype(np.float32)
+    offs, lens, wst, npos, planted = [], [], [], [], []
+    for k in range(12):
+        m = int(rng.integers(12000, 60000))                       # a subtitle event: 1 - 5 s at 12 kHz
+        a = int(rng.integers(5 * PAIR, n - 5 * PAIR - m))
+        ws = a - int(rng.integers(PAIR, 4 * PAIR))
+        p = 8 * PAIR + int(rng.integers(0, 5000))
+        offs.append(a); lens.append(m); wst.append(ws); npos.append(min(p, n - ws - m + 1)); planted.append(a - ws)
+    idx, score, b = _run(dst, src, offs, lens, wst, npos, method)
+    d = b.diagnostics()
+    assert d["all_positions"] == 0 and d["max_bound_ratio"] < 1.0 and d["max_bound_ratio_noncandidate"] < 1.0
+    # one pair per search is transformed first; whatever else survives is a fraction of the rest
+    assert b.fft_pairs >= 9 * len(offs)
+    assert len(offs) <= d["pairs_transformed"] <= b.fft_pairs // 3, (d["pairs_transformed"], b.fft_pairs)
+    for k in range(len(offs)):
+        ok, osc, row = _oracle(oracle, dst, src, offs[k], lens[k], wst[k], npos[k], method)
+        assert int(idx[k]) == ok == planted[k]
+        assert abs(float(score[k]) - osc) <= 1e-4 * abs(osc) + 2.5e-7
+
+
+def test_match_on_a_pair_boundary_and_at_both_ends_of_the_window(oracle):
+    n = 30 * PAIR
+    dst = _stream(n, 3)
+    rng = np.random.default_rng(4)
+    src = (dst + rng.standard_normal(n).astype(np.float32) * 0.01).clip(0, 1).astype(np.float32)
+    m = 20000
+    cases = []
+    for a in (10 * PAIR, 10 * PAIR - 1, 10 * PAIR + 1, 10 * PAIR + 12288, 10 * PAIR + 12287):     # absolute positions of the match
+        cases.append((a, a - 3 * PAIR - 77, 7 * PAIR))          # somewhere inside the window
+        cases.append((a, a, 5 * PAIR))                          # the very first position of the window
+        cases.append((a, a - 5 * PAIR + 1, 5 * PAIR))           # the very last one
+    offs = [c[0] for c in cases]; wst = [c[1] for c in cases]; npos = [c[2] for c in cases]
+    idx, score, b = _run(dst, src, offs, [m] * len(cases), wst, npos)
+    for k, (a, ws, p) in enumerate(cases):
+        ok, osc, _ = _oracle(oracle, dst, src, a, m, ws, p)
+        assert int(idx[k]) == ok == a - ws, (k, int(idx[k]), ok, a - ws)
+        assert abs(float(score[k]) - osc) <= 1e-4 * osc + 2.5e-7
+
+
+def test_the_first_of_two_exact_copies_in_different_pairs_wins():
+    """The same passage twice, several pairs apart, dyadic samples (every sum exact): an exact tie.  The pair that is transformed
+    first may be either; the other one's lower bound is not ABOVE the tie's score, so it is transformed too and the lowest
+    position wins (wav.py:186: argmin takes the first)."""
+    n = 30 * PAIR
+    rng = np.random.default_rng(5)
+    dst = (rng.integers(0, 64, n) / 64.0).astype(np.float32)
+    m = 9000
+    passage = dst[3 * PAIR + 100: 3 * PAIR + 100 + m].copy()
+    for later in (9 * PAIR + 5000, 14 * PAIR + 17):
+        dst[later:later + m] = passage
+    src = np.concatenate([np.zeros(50, np.float32), passage])
+    ws = 2 * PAIR + 11
+    idx, score, b = _run(dst, src, [50], [m], [ws], [16 * PAIR])
+    assert int(idx[0]) == 3 * PAIR + 100 - ws and float(score[0]) == 0.0
+    assert b.diagnostics()["pairs_transformed"] >= 3
+
+
+def test_a_poor_match_excludes_nothing_and_is_still_right(oracle):
+    """Pattern and stream unrelated: the best score is what chance gives, every pair's lower bound is below it."""
+    n = 12 * PAIR
+    dst = _stream(n, 6)
+    src = _stream(40000, 7)
+    idx, score, b = _run(dst, src, [100, 5000], [30000, 2000], [PAIR + 5, 2 * PAIR], [8 * PAIR, 6 * PAIR + 333])
+    for k, (off, m, ws, p) in enumerate([(100, 30000, PAIR + 5, 8 * PAIR), (5000, 2000, 2 * PAIR, 6 * PAIR + 333)]):
+        ok, osc, row = _oracle(oracle, dst, src, off, m, ws, p)
+        assert abs(float(score[k]) - osc) <= 1e-4 * osc + 2.5e-7
+        assert int(idx[k]) == ok or abs(float(row[int(idx[k])]) - osc) <= 2.5e-7
+    assert b.diagnostics()["pairs_transformed"] >= 0.5 * b.fft_pairs
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint8])
+def test_patterns_too_short_for_the_window_energy_bound(oracle, dtype):
+    """Fewer than two stretches of the coarse table inside a window: no lower bound of its energy, nothing excluded."""
+    n = 8 * PAIR
+    x = _stream(n, 8)
+    if dtype == np.uint8:
+        x = (x * 255).astype(np.uint8)
+    offs, lens = [1000, 2000, 3000, 4000], [1, 200, 511, 513]
+    wst, npos = [PAIR] * 4, [3 * PAIR + 7] * 4
+    idx, score, b = _run(x, x, offs, lens, wst, npos)
+    for k in range(4):
+        ok, osc, row = _oracle(oracle, x, x, offs[k], lens[k], wst[k], npos[k])
+        assert float(score[k]) == osc == 0.0 or abs(float(score[k]) - osc) <= 1e-4 * osc + 2.5e-7
+        assert int(idx[k]) == ok or float(row[int(idx[k])]) == osc      # (a 1-sample pattern ties wherever the value recurs)
+
+
+def test_coarse_prefix_table():
+    from sushi_amd.device import DeviceStream
+    from sushi_amd import _native
+    for n in (1, 255, 256, 257, 70001):
+        x = np.random.default_rng(n).random(n, dtype=np.float32)
+        d = DeviceStream(x)
+        c = d._view(_native.VIEW_COARSE, __import__("torch").float64).cpu().numpy()
+        nc = n // 256 + 2
+        assert c.shape[0] == 2 * nc
+        s2, s1 = d.s2.cpu().numpy(), d.s1.cpu().numpy()
+        e = np.minimum(np.arange(nc) * 256, n)
+        assert (c[:nc] == s2[e]).all() and (c[nc:] == s1[e]).all()
