@@ -109,6 +109,8 @@ def lib():
     L.sushi_hip_batch_run.argtypes = [vp, dbl, vp, vp, vp]
     L.sushi_hip_batch_diagnostics.restype = ci
     L.sushi_hip_batch_diagnostics.argtypes = [vp, ctypes.POINTER(BatchDiag), vp, vp]
+    L.sushi_hip_batch_pair_bounds.restype = ci
+    L.sushi_hip_batch_pair_bounds.argtypes = [vp, vp, vp, ctypes.POINTER(i64)]
     L.sushi_hip_batch_destroy.restype = None
     L.sushi_hip_batch_destroy.argtypes = [vp]
     L.sushi_hip_fft_layout.restype = ci

@@ -27,7 +27,8 @@ UNITS = [
     # -fno-slp-vectorize: the SLP pass packs the complex MACs into v_pk_fma_f32 and pays for it in
     # register shuffles (v_mov / accvgpr traffic); plain v_fma_f32 already issues at the f32 peak rate.
     ("sushi_fft", ["-fno-slp-vectorize"],
-     [os.path.join(CSRC, "fft_core.hpp"), os.path.join(CSRC, "mac_core.hpp"), TWIDDLE_INC, os.path.join(CSRC, "_gen_dft16_f16.inc")]),
+     [os.path.join(CSRC, "fft_core.hpp"), os.path.join(CSRC, "mac_core.hpp"), TWIDDLE_INC, os.path.join(CSRC, "_gen_dft16_f16.inc"),
+      os.path.join(CSRC, "_gen_dft16_f16_bound.inc")]),
 ]
 
 
@@ -83,6 +84,32 @@ def write_dft16_operands():
     return DFT16_INC
 
 
+DFT16H_INC = os.path.join(CSRC, "_gen_dft16_f16_bound.inc")
+
+
+def write_dft16_bound_operands():
+    """The B operands of bound_kernel's first pass (fft_core.hpp fft_wave_half_front): the DFT matrix's high halves only, times
+    2^-10 -- [real parts of the result, imaginary parts][lane] x 8 halves as four 32-bit words."""
+    import numpy as np
+    words = []
+    for form in (0, 1):
+        vals = np.empty((64, 8), np.float64)
+        for l in range(64):
+            for j in range(8):
+                k, n = 8 * (l >> 4) + j, l & 15
+                kk, part = k & 15, k >> 4
+                ang = 2.0 * math.pi * ((n * kk) & 15) / 16.0
+                wr, wi = math.cos(ang), math.sin(ang)
+                vals[l, j] = (wr if part == 0 else -wi) if form == 0 else (wi if part == 0 else wr)
+        words.append(np.ascontiguousarray((vals * 2.0 ** -10).astype(np.float16)).view(np.uint32).reshape(-1))
+    flat = np.concatenate(words)
+    text = "".join("0x%08xu,%s" % (int(v), "\n" if i % 8 == 7 else " ") for i, v in enumerate(flat))
+    if not os.path.exists(DFT16H_INC) or open(DFT16H_INC).read() != text:
+        with open(DFT16H_INC, "w") as f:
+            f.write(text)
+    return DFT16H_INC
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -91,7 +118,8 @@ def _stale(target, deps):
 
 
 def needs_build():
-    if not os.path.exists(TWIDDLE_INC) or not os.path.exists(os.path.join(CSRC, "_gen_dft16_f16.inc")):
+    if not os.path.exists(TWIDDLE_INC) or not os.path.exists(os.path.join(CSRC, "_gen_dft16_f16.inc")) or \
+            not os.path.exists(os.path.join(CSRC, "_gen_dft16_f16_bound.inc")):
         return True
     deps = list(COMMON_DEPS)
     for name, _flags, extra in UNITS:
@@ -105,6 +133,7 @@ def build_native(force=False, verbose=False, defines=(), lib=None, obj_tag=""):
     defines=("-DSUSHI_FFT_LOGN=13",), lib=".../libsushi_hip_n13.so", obj_tag="_n13"."""
     write_twiddles()
     write_dft16_operands()
+    write_dft16_bound_operands()
     lib = lib or LIB
     if not force and not defines and not needs_build():
         return lib

@@ -533,6 +533,150 @@ __device__ __forceinline__ void fft_wave_mfma(const uint4v (&yl)[4], cpx* v, int
     fft_wave_mfma_front<DIR>(yl, v, tid, tw, b);
     fft_wave_mfma_back<DIR>(v, tid, lds, tw);
 }
+// ------------------------------------------------------------------------------------------------------------
+// The same three in-wave passes in PACKED HALVES: a complex value is one 32-bit register (re, im), an addition one
+// v_pk_add_f16, a multiplication by a twiddle a v_pk_mul_f16 and a v_pk_fma_f16 (the swaps and sign changes ride on the
+// instructions' op_sel / neg modifiers), a radix-16 butterfly stage half the instructions of the float32 one.  For
+// bound_kernel only, which needs an UPPER BOUND of the largest |A_n1[k2]| to two digits: every output is a sum of 64 of the
+// pass-1 values times unit factors through at most 8 roundings of 2^-11 and twiddles rounded to 2^-12, so
+//     | |A| computed - |A| | <= (8 * 2^-11 + 2^-11) * 64 * max |pass-1 value| < 0.29 * max |pass-1 value|,
+// which the caller adds.  Values are scaled by 2^-10 on the way in (the DFT matrix operand carries the factor): with |Y(f)|
+// below 2^15.5 nothing can overflow (16 * 16 * 4 terms: 2^25.5 * 2^-10 < 65504).
+// ------------------------------------------------------------------------------------------------------------
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2 h_rot(const h2 a) { return h2{-a.y, a.x}; }                            // times +i
+__device__ __forceinline__ h2 h_cmul(const h2 a, const h2 w) { return a * w.xx + h_rot(a) * w.yy; }
+__device__ __forceinline__ h2 h_splat(const float c) { return h2{(_Float16)c, (_Float16)c}; }
+// lo = e + w o, hi = e - w o for w = exp(+2 pi i q / 32) (the inverse transform's roots)
+__device__ __forceinline__ void h_bfly_root32(const h2 e, const h2 o, const int q, h2& lo, h2& hi) {
+    const float C[9] = {1.0f, 0.98078528040323044913f, 0.92387953251128673848f, 0.83146961230254523708f, 0.70710678118654752440f,
+                        0.55557023301960222474f, 0.38268343236508978178f, 0.19509032201612826785f, 0.0f};
+    switch (q) {
+        case 0: lo = e + o; hi = e - o; return;
+        case 8: lo = e + h_rot(o); hi = e - h_rot(o); return;
+        case 4: { const h2 p = o + h_rot(o); lo = p * h_splat(C[4]) + e; hi = e - p * h_splat(C[4]); return; }
+        case 12: { const h2 p = h_rot(o) - o; lo = p * h_splat(C[4]) + e; hi = e - p * h_splat(C[4]); return; }
+        default: {
+            const float c = q <= 8 ? C[q] : -C[16 - q], sn = q <= 8 ? C[8 - q] : C[q - 8];
+            lo = h_rot(o) * h_splat(sn) + (o * h_splat(c) + e);
+            hi = e * h_splat(2.0f) - lo;
+        }
+    }
+}
+template <int R>
+struct DftH {
+    static __device__ __forceinline__ void run(h2* v) {
+        h2 e[R / 2], o[R / 2];
+#pragma unroll
+        for (int u = 0; u < R / 2; ++u) { e[u] = v[2 * u]; o[u] = v[2 * u + 1]; }
+        DftH<R / 2>::run(e);
+        DftH<R / 2>::run(o);
+#pragma unroll
+        for (int t = 0; t < R / 2; ++t) h_bfly_root32(e[t], o[t], t * (32 / R), v[t], v[t + R / 2]);
+    }
+};
+template <>
+struct DftH<1> {
+    static __device__ __forceinline__ void run(h2*) {}
+};
+// a lane's twiddles of passes 2 and 3 (they depend on the lane only): rounded once from the float32 table
+struct HTwiddles { h2 p2[16]; h2 z1[4], z2[4], z3[4]; };
+__device__ __forceinline__ h2 h_round(const cpx c) { return h2{(_Float16)c.x, (_Float16)c.y}; }
+__device__ __forceinline__ HTwiddles load_htwiddles(const int lane, const cpx* __restrict__ tw) {
+    HTwiddles t;
+    const int e1 = lane & 15;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) t.p2[d] = h_round(cconj(tw[((e1 * d) & 255) * (TWIDDLE_N / 256)]));          // w256^(e1 d), inverse
+    const cpx q3 = cconj(tw[((lane & 15) + 64 * (lane >> 4)) * (TWIDDLE_N / 1024)]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const cpx z = cmul(q3, cconj(tw[e * (TWIDDLE_N / 64)]));                                                 // q3 w64^e
+        const cpx z2 = cmul(z, z);
+        t.z1[e] = h_round(z); t.z2[e] = h_round(z2); t.z3[e] = h_round(cmul(z2, z));
+    }
+    return t;
+}
+// |a|^2 as float32 bits, and the largest of such: for values >= 0 the order of the bit patterns is the order of the values, and an
+// infinity or a NaN (were there ever one) is LARGER than every finite value instead of being dropped, as fmaxf drops a NaN.
+// (The builtin, not an asm statement with the instruction's three-operand form: inside bound_kernel's loop -- not in a
+// straight-line test -- the asm's result register came back holding the INPUT.)
+__device__ __forceinline__ unsigned h_abs2(const h2 a) {
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_fdot2(a, a, 0.f, false));
+}
+__device__ __forceinline__ unsigned h_max_bits(const unsigned a, const unsigned b) { return a > b ? a : b; }
+struct MfmaBh { half8 r, i; };        // the DFT matrix's high halves times 2^-10
+__device__ __forceinline__ MfmaBh load_mfma_bh(const int lane, const uint4v* __restrict__ table) {
+    MfmaBh b;
+    b.r = __builtin_bit_cast(half8, table[lane]);
+    b.i = __builtin_bit_cast(half8, table[64 + lane]);
+    return b;
+}
+// v[4 e3 + e2lo] = 2^-10 A_n1[k2] (the float32 version's layout); max_in2 = the largest |pass-1 value|^2 of this lane (float bits)
+__device__ __forceinline__ void fft_wave_half_front(const uint4v (&yl)[4], h2* v, const HTwiddles& tw, const MfmaBh& b, unsigned& max_in2,
+                                                    h2* pass1_out = nullptr, h2* pass2_out = nullptr, h2* swapped_out = nullptr) {
+    unsigned mi = 0u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        unsigned rr01 = __builtin_amdgcn_perm(yl[g][1], yl[g][0], 0x05040100u), rr23 = __builtin_amdgcn_perm(yl[g][3], yl[g][2], 0x05040100u);
+        unsigned ii01 = __builtin_amdgcn_perm(yl[g][1], yl[g][0], 0x07060302u), ii23 = __builtin_amdgcn_perm(yl[g][3], yl[g][2], 0x07060302u);
+        { const auto r = __builtin_amdgcn_permlane32_swap(rr01, ii01, false, false); rr01 = r[0]; ii01 = r[1]; }
+        { const auto r = __builtin_amdgcn_permlane32_swap(rr23, ii23, false, false); rr23 = r[0]; ii23 = r[1]; }
+        const uint4v aw = {rr01, rr23, ii01, ii23};
+        const half8 a = __builtin_bit_cast(half8, aw);
+        const float4v z = {0.f, 0.f, 0.f, 0.f};
+        const float4v dr = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b.r, z, 0, 0, 0);
+        const float4v di = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b.i, z, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned packed = __builtin_bit_cast(unsigned, h2{(_Float16)dr[i], (_Float16)di[i]});
+            // (seen as two conversions, the value is converted AGAIN, half by half, for every swapped or negated use: opaque from here)
+            asm volatile("" : "+v"(packed));
+            v[4 * g + i] = __builtin_bit_cast(h2, packed);
+            mi = h_max_bits(mi, h_abs2(v[4 * g + i]));
+        }
+    }
+    max_in2 = mi;
+    if (pass1_out) {                                                 // (tools/ubench/half_front_check.hip)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) pass1_out[t] = v[t];
+    }
+#pragma unroll
+    for (int t = 1; t < 16; ++t) v[t] = h_cmul(v[t], tw.p2[t]);     // pass 2: twiddle w256^(e1 d2), then the DFTs over d2
+    DftH<16>::run(v);
+    if (pass2_out) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) pass2_out[t] = v[t];
+    }
+    // (hipcc 7.2 miscompiles these swaps when their two results are bit-cast straight to half vectors -- the second result
+    // becomes a copy of the first: tools/ubench/half_front_check.hip found it -- so both results pass an opaque asm first)
+    auto swap32 = [](h2& x, h2& y) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+        unsigned ra = r[0], rb = r[1];
+        asm volatile("" : "+v"(ra), "+v"(rb));
+        x = __builtin_bit_cast(h2, ra); y = __builtin_bit_cast(h2, rb);
+    };
+    auto swap16 = [](h2& x, h2& y) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+        unsigned ra = r[0], rb = r[1];
+        asm volatile("" : "+v"(ra), "+v"(rb));
+        x = __builtin_bit_cast(h2, ra); y = __builtin_bit_cast(h2, rb);
+    };
+#pragma unroll
+    for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if ((r & 4) == 0) swap16(v[r], v[r + 4]);
+    if (swapped_out) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) swapped_out[t] = v[t];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {                                    // pass 3: twiddle (q3 w64^e2lo)^d3, 4-point DFTs over d3
+        h2 q[4] = {v[e], h_cmul(v[4 + e], tw.z1[e]), h_cmul(v[8 + e], tw.z2[e]), h_cmul(v[12 + e], tw.z3[e])};
+        DftH<4>::run(q);
+        v[e] = q[0]; v[4 + e] = q[1]; v[8 + e] = q[2]; v[12 + e] = q[3];
+    }
+}
 #endif  // __HIPCC__
 
 }  // namespace sushi_fft

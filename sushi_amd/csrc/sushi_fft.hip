@@ -144,6 +144,10 @@ __device__ __attribute__((aligned(16))) const unsigned g_dft16_b[4 * 64 * 4] = {
 __device__ __forceinline__ sushi_fft::MfmaB dft16_operands(const int tid) {
     return sushi_fft::load_mfma_b(tid, reinterpret_cast<const sushi_fft::uint4v*>(g_dft16_b));
 }
+// ... and of bound_kernel's first pass: the matrix's high halves times 2^-10 (generated by sushi_amd/build.py)
+__device__ __attribute__((aligned(16))) const unsigned g_dft16_bh[2 * 64 * 4] = {
+#include "_gen_dft16_f16_bound.inc"
+};
 
 // ------------------------------------------------------------------------------------------
 // Destination-stream spectra
@@ -928,6 +932,10 @@ __device__ __forceinline__ float wave_reduce_f32(float v, Op op) {         // wa
 __device__ __forceinline__ float wave_sum_f32(float v) { return wave_reduce_f32(v, [](float a, float b) { return a + b; }); }
 __device__ __forceinline__ float wave_min_f32(float v) { return wave_reduce_f32(v, [](float a, float b) { return fminf(a, b); }); }
 __device__ __forceinline__ float wave_max_f32(float v) { return wave_reduce_f32(v, [](float a, float b) { return fmaxf(a, b); }); }
+// (bit patterns of floats >= 0: the integer order is the float order, and nothing is dropped for being a NaN)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    return __float_as_uint(wave_reduce_f32(__uint_as_float(v), [](float a, float b) { return __uint_as_float(__float_as_uint(a) > __float_as_uint(b) ? __float_as_uint(a) : __float_as_uint(b)); }));
+}
 
 template <int METHOD>
 __global__ __launch_bounds__(FT, 8)
@@ -1096,15 +1104,15 @@ struct BoundArgs {
 // waves take neighbouring items: the sixteen shares of a pair are read at about the same time.  Results are added to the pair's
 // accumulators (zeroed by a memset): acc[2 pr] += max |A|, acc[2 pr + 1] = max(row energy of a wave) as float bits.
 constexpr int BOUND_THREADS = 256;
-__global__ __launch_bounds__(BOUND_THREADS, 3)
+__global__ __launch_bounds__(BOUND_THREADS, 4)
 void bound_kernel(BoundArgs a) {
     const int lane = threadIdx.x & 63;
     const int waves = gridDim.x * (BOUND_THREADS / 64);
     const int gw = blockIdx.x * (BOUND_THREADS / 64) + (threadIdx.x >> 6);
     const int64_t n_items = (int64_t)a.n_pairs * 16;
-    // the transform's per-lane constants do not depend on the wave (tw.p4, which does, belongs to the pass that is not run)
-    const sushi_fft::MfmaB mb = dft16_operands(lane);
-    const sushi_fft::WTwiddles tw = sushi_fft::load_wtwiddles<1>(lane, twiddles());
+    // the transform's per-lane constants do not depend on the wave: loaded (and rounded to halves) once
+    const sushi_fft::MfmaBh mb = sushi_fft::load_mfma_bh(lane, reinterpret_cast<const sushi_fft::uint4v*>(g_dft16_bh));
+    const sushi_fft::HTwiddles tw = sushi_fft::load_htwiddles(lane, twiddles());
     const sushi_fft::uint4v* __restrict__ yh = reinterpret_cast<const sushi_fft::uint4v*>(a.y);
     auto load_item = [&](const int64_t it, sushi_fft::uint4v (&yl)[4]) {
         const size_t pr = (size_t)(it >> 4);
@@ -1129,15 +1137,21 @@ void bound_kernel(BoundArgs a) {
                 const h2 h = __builtin_bit_cast(h2, yl[u][j]);
                 q2 = __builtin_amdgcn_fdot2(h, h, q2, false);
             }
-        cpx v[sushi_fft::PER];
-        sushi_fft::fft_wave_mfma_front<1>(yl, v, lane, tw, mb);
-        float m2 = 0.f;
+        // the three in-wave passes in packed halves (fft_core.hpp): 2^-10 A_n1[k2], good to two digits -- enough for a bound
+        sushi_fft::h2 v[sushi_fft::PER];
+        unsigned in2;
+        sushi_fft::fft_wave_half_front(yl, v, tw, mb, in2);
+        unsigned m2 = 0u;                                                  // largest |value|^2 as float bits (fft_core.hpp h_abs2)
 #pragma unroll
-        for (int r = 0; r < sushi_fft::PER; ++r) m2 = fmaxf(m2, __builtin_fmaf(v[r].x, v[r].x, v[r].y * v[r].y));
-        const float wm = wave_max_f32(m2), qw = wave_sum_f32(q2);
+        for (int r = 0; r < sushi_fft::PER; ++r) m2 = sushi_fft::h_max_bits(m2, sushi_fft::h_abs2(v[r]));
+        const unsigned wm = wave_max_u32(m2), wi = wave_max_u32(in2);
+        const float qw = wave_sum_f32(q2);
         if (lane == 0) {
             const size_t pr = (size_t)(it >> 4);
-            atomicAdd(a.acc + 2 * pr, sqrtf(wm) * 1.000002f);
+            // the largest |A|: what the halves gave, their rounding (header of the packed-half passes), the 2^-10 undone
+            float bw = (sqrtf(__uint_as_float(wm)) * 1.002f + 0.29f * sqrtf(__uint_as_float(wi))) * 1024.0f;
+            if (wm >= 0x7f800000u || wi >= 0x7f800000u) bw = __builtin_inff();
+            atomicAdd(a.acc + 2 * pr, bw);
             atomicMax(reinterpret_cast<unsigned*>(a.acc + 2 * pr + 1), __float_as_uint(qw));
         }
 #pragma unroll
@@ -1932,9 +1946,9 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             ba.acc = (float*)(wsp + wl.acc);
             if (hipMemsetAsync(ba.acc, 0, (size_t)sbt.pairs * 2 * sizeof(float), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
             {
-                // persistent waves: three workgroups of four per CU (the kernel's register budget), fewer for a small batch
+                // persistent waves: four workgroups of four per CU (the kernel's register budget), fewer for a small batch
                 const int64_t want = (sbt.pairs * 16 + BOUND_THREADS / 64 - 1) / (BOUND_THREADS / 64);
-                const unsigned grid = (unsigned)std::min<int64_t>(want, 256 * 3);
+                const unsigned grid = (unsigned)std::min<int64_t>(want, 256 * 4);
                 hipLaunchKernelGGL(bound_kernel, dim3(grid), dim3(BOUND_THREADS), 0, st, ba);
                 if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
                 if (ccm) hipLaunchKernelGGL(slb_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3((unsigned)((sbt.pairs + 3) / 4)), dim3(256), 0, st, ba);
@@ -2021,6 +2035,21 @@ int sushi_hip_batch_diagnostics(SushiHipBatch* b, SushiHipBatchDiag* diag, float
     }
     return SUSHI_HIP_OK;
 } catch (...) { return SUSHI_HIP_ENOSPACE; }        // std::bad_alloc etc.: nothing crosses the C boundary
+
+int sushi_hip_batch_pair_bounds(SushiHipBatch* b, float* slb_host, float* acc_host, int64_t* n_pairs) try {
+    if (!b || !n_pairs) return SUSHI_HIP_EINVAL;
+    if (!b->ran || b->path != SUSHI_HIP_PATH_FFT || b->plan.subs.empty()) { *n_pairs = 0; return SUSHI_HIP_OK; }
+    if (hipStreamSynchronize(b->last_stream) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+    const SubBatch& sbt = b->plan.subs.back();
+    const WsLayout wl = ws_layout(sbt.pairs, sbt.segs, sbt.b0 - sbt.a0);
+    const int64_t cap = *n_pairs;
+    *n_pairs = sbt.pairs;
+    if (cap < sbt.pairs) return SUSHI_HIP_ENOSPACE;
+    const char* wsp = b->mem + b->lay.ws;
+    if (slb_host && hipMemcpy(slb_host, wsp + wl.slb, (size_t)sbt.pairs * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+    if (acc_host && hipMemcpy(acc_host, wsp + wl.acc, (size_t)sbt.pairs * 2 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+    return SUSHI_HIP_OK;
+} catch (...) { return SUSHI_HIP_ENOSPACE; }
 
 int sushi_hip_profile_begin(void) {
     for (ProfCall& c : g_prof)

@@ -287,6 +287,16 @@ class SearchBatch(object):
             out["ranking_err"], out["flagged_per_search"] = err, flg
         return out
 
+    def pair_bounds(self):
+        """FFT path, after run(): (slb float32[pairs], acc float32[pairs, 2]) of the last sub-batch -- every block pair's lower
+        bound of its scores (-inf: none) and what it was made from (sushi_hip_batch_pair_bounds).  Synchronises."""
+        n = ctypes.c_int64(int(self.fft_pairs))
+        slb = np.empty(int(self.fft_pairs), np.float32)
+        acc = np.empty((int(self.fft_pairs), 2), np.float32)
+        _native.check(_native.lib().sushi_hip_batch_pair_bounds(self._handle, slb.ctypes.data, acc.ctypes.data, ctypes.byref(n)),
+                      "sushi_hip_batch_pair_bounds")
+        return slb[:n.value], acc[:n.value]
+
     def ranking_errors(self):
         """FFT path: |f32 FFT score - exact score| at every search's result position in the last run()
         (0 for searches the tile kernel finished)."""
