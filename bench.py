@@ -583,8 +583,10 @@ def main():
                     traffic_note = "stale: PMC passes were taken on kernel sources %s, this is %s" % (
                         entry.get("kernel_source_digest"), digest)
                 else:
-                    kern = entry["kernels"][kname]
-                    traffic_bytes = kern["fetch_bytes"] + kern["write_bytes"]
+                    kerns = [entry["kernels"][kn] for kn in _native.STAGE_KERNEL_SETS[dom] if kn in entry["kernels"]]
+                    if not kerns:
+                        raise KeyError(kname)
+                    traffic_bytes = float(sum(kk["fetch_bytes"] + kk["write_bytes"] for kk in kerns))
                     traffic = traffic_bytes / (dom_ms * 1e-3) / 1e9
                     step_traffic = float(sum(k["fetch_bytes"] + k["write_bytes"] for k in entry["kernels"].values()))
                     traffic_note = "%s @ %s" % (entry.get("source"), entry.get("source_commit"))

@@ -26,6 +26,10 @@ NSTAGES = 6
 STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish", "bound")
 STAGE_KERNELS = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "ifft_kernel", "refine": "refine_kernel",
                  "finish": "collect_kernel+exact_tiles_kernel+unpack_keys_kernel", "bound": "bound_kernel"}
+# every kernel a stage's HIP-event span covers (profiles/pmc_traffic.json is keyed by kernel)
+STAGE_KERNEL_SETS = {"tspec": ("tspec_kernel",), "mac": ("mac_kernel", "mac_long_kernel"),
+                     "ifft": ("ifft_kernel", "pilot_kernel", "survivor_kernel"), "refine": ("refine_kernel",),
+                     "finish": ("collect_kernel", "exact_tiles_kernel"), "bound": ("bound_kernel", "slb_kernel")}
 
 # struct SushiHipRequest, 24 bytes
 REQUEST_DTYPE = np.dtype([("tmpl_off", "<i8"), ("win_start", "<i8"), ("tmpl_len", "<i4"), ("n_pos", "<i4")], align=True)

@@ -36,8 +36,9 @@ if tcp_summary:
         if r.get('TCP_TCC_WRITE_REQ_sum'):
             tcp[r['kernel'].split('<')[0]] = float(r['TCP_TCC_WRITE_REQ_sum']) * 64.0
 res = {}
-for k, fetch_scale in (('ifft_kernel', 2.0), ('mac_kernel', 2.0), ('tspec_kernel', 1.0), ('refine_kernel', 1.0),
-                       ('collect_kernel', 2.0), ('exact_tiles_kernel', 1.0)):
+for k, fetch_scale in (('ifft_kernel', 2.0), ('mac_kernel', 2.0), ('mac_long_kernel', 2.0), ('bound_kernel', 2.0), ('tspec_kernel', 1.0),
+                       ('refine_kernel', 1.0), ('collect_kernel', 2.0), ('exact_tiles_kernel', 1.0), ('slb_kernel', 1.0),
+                       ('pilot_kernel', 1.0), ('survivor_kernel', 1.0)):
     if k not in rows or not rows[k].get('FETCH_SIZE'):
         continue
     if rows[k].get('WRITE_SIZE'):
