@@ -263,6 +263,9 @@ def main():
     ap.add_argument("--hard-frac", type=float, default=0.0,
                     help="fraction of the events cut from digital silence / a held tone / a repeated jingle "
                          "(tie-saturated searches); 0 = the BASELINE workload")
+    ap.add_argument("--profile-only", action="store_true",
+                    help="no oracle leg at all (no forked workers: rocprofv3's counter passes hang waiting for them); the line's "
+                         "parity block then holds the planted-offset check only -- for profiler runs, never for a reported line")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the TIMING of the oracle (cpu_baseline: null); the parity sample is still run")
     ap.add_argument("--cpu-sample", type=int, default=64, help="searches of the workload the oracle is run on, at least")
@@ -361,7 +364,7 @@ def main():
     # Always: the parity sample (>= --cpu-sample evenly spaced searches + every search cut from tie-saturated material).
     # N = 1 and not --no-cpu-baseline: over a larger sample, timed = cpu_baseline.
     cpu, cpu_results = None, {}
-    if rank == 0 and not dry:
+    if rank == 0 and not dry and not args.profile_only:
         timed = world == 1 and not args.no_cpu_baseline
         cpu, cpu_results = oracle_leg(dst.data[0], src.data[0], offs, lens, wst, npos, args.method,
                                       forced=np.nonzero(hard_mask)[0], timed=timed, min_sample=args.cpu_sample,

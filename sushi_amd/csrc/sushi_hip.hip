@@ -249,77 +249,59 @@ template <typename T> struct WideLoad;
 template <> struct WideLoad<float> { static constexpr int N = 4; struct __attribute__((packed, aligned(4))) V { float v[4]; }; };
 template <> struct WideLoad<uint8_t> { static constexpr int N = 16; struct __attribute__((packed, aligned(1))) V { uint8_t v[16]; }; };
 
-// NT tasks of one search over one chunk of the pattern: a task is FFT_AUDIT consecutive positions from its own window pointer
-// on (a candidate is a task whose first position is the one that counts).  Position q of a task sees the window w + q, so a
-// step's window samples serve all of a task's positions, and the pattern samples serve all tasks: per step K pattern loads and
-// K window loads per task (the last window vector of a step is the first of the next).  Every position keeps its own chain in
-// the canonical order -- one fused multiply-add per sample, samples in order -- so its value does not depend on what it was
-// bundled with.  A thread walks its own chunk: neighbouring lanes read 2 KB apart, every load instruction touches 64 lines
-// whatever its width (which is what this stage's time consists of: fewer, wider instructions); the loads of step i + 1 are
-// issued before the additions of step i.  room[i]: window elements readable from w[i] on.
-template <typename T, int NT>
-__device__ __forceinline__ void chunk_bundle(const T* __restrict__ t, const T* const (&w)[NT], const int mc,
-                                             const int64_t (&room)[NT], double (&acc)[NT][FFT_AUDIT]) {
+// NPOS consecutive positions of one search over one chunk of the pattern (a candidate is the first of four; an audit run is four,
+// the four runs of one pair sixteen): position q sees the window w + q, so a step's window samples serve all of them -- per step
+// K pattern loads and K window loads (the window vectors behind the step's own are the first of the next step's).  Every
+// position keeps its own chain in the canonical order -- one fused multiply-add per sample, samples in order -- so its value
+// does not depend on what it was evaluated with.  A thread walks its own chunk: neighbouring lanes read 2 KB apart, every
+// load instruction touches 64 lines whatever its width; the loads of step i + 1 are issued before the additions of step i.
+// room: window elements readable from w on.
+template <typename T, int NPOS>
+__device__ __forceinline__ void chunk_run(const T* __restrict__ t, const T* __restrict__ w, const int mc, const int64_t room,
+                                          double (&acc)[NPOS]) {
     typedef typename WideLoad<T>::V V;
     constexpr int N = WideLoad<T>::N;
     constexpr int K = N >= 16 ? 1 : 2;                   // a step = 16 uint8 / 8 float32 samples
     constexpr int STEP = K * N;
-    static_assert(FFT_AUDIT - 1 <= N, "a step's overhang is one more vector");
+    constexpr int OV = (NPOS - 1 + N - 1) / N;           // vectors a step's positions reach past the step's own samples
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int q = 0; q < FFT_AUDIT; ++q) acc[i][q] = 0.0;
-    // whole steps whose window loads (this step's K + 1 vectors, the next step's K) stay inside every task's room
-    int steps = mc / STEP;
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int64_t fit = room[i] >= (int64_t)(STEP + N) ? (room[i] - N) / STEP : 0;
-        steps = fit < (int64_t)steps ? (int)fit : steps;
-    }
-    V a[K], an[K], b[NT][K + 1], bn[NT][K];
+    for (int q = 0; q < NPOS; ++q) acc[q] = 0.0;
+    // whole steps whose window loads (this step's K + OV vectors, the next step's K) stay inside `room`
+    const int64_t fit = room >= (int64_t)(STEP + N * OV) ? (room - N * OV) / STEP : 0;
+    const int steps = fit < (int64_t)(mc / STEP) ? (int)fit : mc / STEP;
+    V a[K], an[K], b[K + OV], bn[K];
     if (steps > 0) {
 #pragma unroll
         for (int j = 0; j < K; ++j) a[j] = *reinterpret_cast<const V*>(t + N * j);
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int j = 0; j < K + 1; ++j) b[i][j] = *reinterpret_cast<const V*>(w[i] + N * j);
+        for (int j = 0; j < K + OV; ++j) b[j] = *reinterpret_cast<const V*>(w + N * j);
     }
     for (int s = 0; s < steps; ++s) {
         const int mn = (s + 1 < steps ? s + 1 : s) * STEP;          // (the last step re-requests itself: unconditional loads)
 #pragma unroll
         for (int j = 0; j < K; ++j) an[j] = *reinterpret_cast<const V*>(t + mn + N * j);
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int j = 0; j < K; ++j) bn[i][j] = *reinterpret_cast<const V*>(w[i] + mn + N * (j + 1));
+        for (int j = 0; j < K; ++j) bn[j] = *reinterpret_cast<const V*>(w + mn + N * (OV + j));
 #pragma unroll
         for (int e = 0; e < STEP; ++e) {
             const double te = (double)a[e / N].v[e % N];
 #pragma unroll
-            for (int i = 0; i < NT; ++i)
-#pragma unroll
-                for (int q = 0; q < FFT_AUDIT; ++q)
-                    acc[i][q] = __builtin_fma(te, (double)b[i][(e + q) / N].v[(e + q) % N], acc[i][q]);
+            for (int q = 0; q < NPOS; ++q) acc[q] = __builtin_fma(te, (double)b[(e + q) / N].v[(e + q) % N], acc[q]);
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) a[j] = an[j];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            b[i][0] = b[i][K];
+        for (int j = 0; j < OV; ++j) b[j] = b[j + K];
 #pragma unroll
-            for (int j = 0; j < K; ++j) b[i][j + 1] = bn[i][j];
-        }
+        for (int j = 0; j < K; ++j) b[OV + j] = bn[j];
     }
     for (int m = steps * STEP; m < mc; ++m) {
         const double te = (double)t[m];
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int q = 0; q < FFT_AUDIT; ++q) {
-                const int64_t x = (int64_t)m + q < room[i] ? (int64_t)m + q : room[i] - 1;     // (past the stream: a position nobody reads)
-                acc[i][q] = __builtin_fma(te, (double)w[i][x], acc[i][q]);
-            }
+        for (int q = 0; q < NPOS; ++q) {
+            const int64_t x = (int64_t)m + q < room ? (int64_t)m + q : room - 1;       // (past the stream: a position nobody reads)
+            acc[q] = __builtin_fma(te, (double)w[x], acc[q]);
+        }
     }
 }
 
@@ -461,7 +443,7 @@ __global__ void unpack_keys_kernel(const unsigned long long* __restrict__ keys, 
 constexpr int RCAP = 128;
 constexpr int RAUD = AUDIT_RUNS * FFT_AUDIT;      // audited non-candidate positions per search
 constexpr int RENT = RCAP + RAUD;                // list entries: candidates, then audit positions
-constexpr int REFINE_THREADS = 384;              // thread <-> (task, chunk): the usual search (one candidate + AUDIT_RUNS runs, a 3 s pattern = 71 chunks) in one round
+constexpr int REFINE_THREADS = 256;              // thread <-> (task, chunk): the usual search (its candidate + one audit stretch, a 3 s pattern = 71 chunks) in one round
 
 // Entries [0, n_cand) of the list are candidates; entries [n_cand, n_all) are audit positions: NOT selected, with their plain
 // f32 scores, evaluated like the others and only checked against the bound (the two-sided check of the error model).
@@ -510,8 +492,9 @@ __device__ __forceinline__ void refine_body(const RefineParams& a, const int s_i
         }
         rerr[k] = err;
     };
-    // thread <-> (task, chunk): R tasks at a time (all of the usual search's five in one round); then one thread per
-    // (task, position) adds its chunk sums in order.  Patterns of more chunks than threads: one task at a time, chunk groups.
+    // thread <-> (task, chunk): R tasks at a time (the usual search's two -- its candidate and the sixteen audit positions of its
+    // one transformed pair -- in one round); then one thread per (task, position) adds its chunk sums in order.  Patterns of
+    // more chunks than threads: one task at a time, chunk groups.
     constexpr int nthr = REFINE_THREADS;
     const bool small = n_chunks <= nthr;
     const int R = small ? nthr / n_chunks : 1;
@@ -521,42 +504,51 @@ __device__ __forceinline__ void refine_body(const RefineParams& a, const int s_i
         const int t = t0 + slot;
         const bool have = slot < R && t < n_tasks;
         const int64_t p = have ? (int64_t)key_pos(list[tent[t]]) : 0;
+        const bool wide = have && tlen[t] > FFT_AUDIT;            // an audit stretch of RAUD positions
         double tot = 0.0;
         for (int c0 = 0; c0 < n_chunks; c0 += cpr) {
             const int cl = small ? tid - slot * n_chunks : tid;   // chunk inside the round
             const int ch = c0 + cl;
-            double v[1][FFT_AUDIT] = {{0.0, 0.0, 0.0, 0.0}};
             if (have && ch < n_chunks) {
                 const int m0 = ch * XM;
-                const T* wc[1] = {Wp + p + m0};
-                const int64_t rc[1] = {a.r.dst_len - (sd.win_start + p + m0)};
-                chunk_bundle<T, 1>(Tp + m0, wc, min(XM, M - m0), rc, v);
-            }
+                const int64_t room = a.r.dst_len - (sd.win_start + p + m0);
+                if (wide) {
+                    double v[RAUD];
+                    chunk_run<T, RAUD>(Tp + m0, Wp + p + m0, min(XM, M - m0), room, v);
 #pragma unroll
-            for (int q = 0; q < FFT_AUDIT; ++q) part[FFT_AUDIT * tid + q] = v[0][q];
+                    for (int q = 0; q < RAUD; ++q) part[RAUD * tid + q] = v[q];
+                } else {
+                    double v[FFT_AUDIT];
+                    chunk_run<T, FFT_AUDIT>(Tp + m0, Wp + p + m0, min(XM, M - m0), room, v);
+#pragma unroll
+                    for (int q = 0; q < FFT_AUDIT; ++q) part[RAUD * tid + q] = v[q];
+                }
+            }
             __syncthreads();
-            if (tid < FFT_AUDIT * R) {
-                const int fs = tid / FFT_AUDIT, q = tid % FFT_AUDIT;
-                const int cn = min(cpr, n_chunks - c0);
-                for (int c = 0; c < cn; ++c) tot += part[FFT_AUDIT * (fs * cpr + c) + q];
+            if (tid < RAUD * R) {
+                const int fs = tid / RAUD, q = tid % RAUD;
+                if (t0 + fs < n_tasks && q < tlen[t0 + fs]) {
+                    const int cn = min(cpr, n_chunks - c0);
+                    for (int c = 0; c < cn; ++c) tot += part[RAUD * (fs * cpr + c) + q];
+                }
             }
             __syncthreads();
         }
-        if (tid < FFT_AUDIT * R) {
-            const int fs = tid / FFT_AUDIT, q = tid % FFT_AUDIT;
+        if (tid < RAUD * R) {
+            const int fs = tid / RAUD, q = tid % RAUD;
             if (t0 + fs < n_tasks && q < tlen[t0 + fs]) finish(tent[t0 + fs] + q, tot);
         }
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(REFINE_THREADS, 4)
+__global__ __launch_bounds__(REFINE_THREADS, 3)
 void refine_kernel(RefineParams a) {
     __shared__ unsigned long long list[RENT], rkey[RENT];
     __shared__ int lpair[RENT];
     __shared__ float rerr[RENT];
     __shared__ short tent[RENT], tlen[RENT];
-    __shared__ double part[FFT_AUDIT * REFINE_THREADS];
+    __shared__ double part[RAUD * REFINE_THREADS];
     __shared__ int cnt, ovf, violated, n_all_s, n_tasks_s;
     __shared__ unsigned wg_ratio[2];             // this search's largest error / bound ratios (float bits): candidates, audit
     const int tid = threadIdx.x;
@@ -609,7 +601,17 @@ void refine_kernel(RefineParams a) {
                 const int pa = pa0 + j < lay.n_pairs ? pa0 + j : pa0 + j - lay.n_pairs;
                 if (rows[(size_t)pa * FFT_ROW + FFT_CAND + 1] != NO_KEY) sel[n_sel++] = pa;      // transformed: it left its error bound
             }
-            for (int r = 0; r < AUDIT_RUNS && n_sel > 0; ++r) {
+            bool wide = false;
+            if (n_sel == 1) {
+                // the four runs of one pair are sixteen consecutive positions: one task, the window loads of ONE position
+                wide = true;
+                for (int q = 0; q < RAUD; ++q) wide = wide && rows[(size_t)sel[0] * FFT_ROW + FFT_CAND + 2 + q] != NO_KEY;
+                if (wide) {
+                    tent[n_tasks] = (short)n_all; tlen[n_tasks] = RAUD; ++n_tasks;
+                    for (int q = 0; q < RAUD; ++q) { list[n_all] = rows[(size_t)sel[0] * FFT_ROW + FFT_CAND + 2 + q]; lpair[n_all] = sel[0]; ++n_all; }
+                }
+            }
+            for (int r = 0; r < AUDIT_RUNS && n_sel > 0 && !wide; ++r) {
                 const int pa = sel[r % n_sel], run = r / n_sel;
                 unsigned long long key[FFT_AUDIT];
                 int valid = 0;

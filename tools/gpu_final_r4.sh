@@ -8,13 +8,13 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export SUSHI_BENCH_CACHE=/tmp/sushi_bench_cache
 run_wl() {
   name=$1; key=$2; args=$3; steps=${4:-5}
-  B="python bench.py --steps $steps --warmup 1 --no-cpu-baseline --cpu-sample 2 $args"
+  B="python bench.py --steps $steps --warmup 1 --profile-only $args"            # (no forked oracle workers under the profiler)
   timeout 400 $B > $O/warm_$name.json 2> $O/warm_$name.err            # builds the stream cache
   rm -rf gpurun_out/prof_*
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -o kt -- $B > $O/kt_$name.log 2>&1
   cp gpurun_out/prof_kt/kt_kernel_stats.csv $O/${name}_kernel_stats.csv
   timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -o fetch -- $B > $O/fetch_$name.log 2>&1
-  timeout 90 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -o write -- $B > $O/write_$name.log 2>&1 || echo "WRITE_SIZE pass of $name cut by its timeout" | tee -a $O/notes.txt
+  timeout 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -o write -- $B > $O/write_$name.log 2>&1 || echo "WRITE_SIZE pass of $name cut by its timeout" | tee -a $O/notes.txt
   python tools/summarize_pmc.py $O/${name}_pmc_summary.csv $(find gpurun_out/prof_fetch gpurun_out/prof_write -name '*counter_collection.csv' 2>/dev/null)
   python tools/make_pmc_traffic.py $O/${name}_pmc_summary.csv profiles/pmc_traffic.json "$key" "$COMMIT" > /dev/null || echo "no pmc_traffic entry for $name" | tee -a $O/notes.txt
   head -8 $O/${name}_kernel_stats.csv | cut -c1-150
