@@ -169,6 +169,18 @@ __device__ __forceinline__ float finish_ccoeff_normed(double corr_u, double wS1,
     return (float)r;
 }
 
+// Whether finish_ccoeff_normed ignores the cross term at this window: a flat pattern, or a window cv2 takes for flat (its
+// variance sum inside 10 FLT_EPSILON of its energy: t = 0, the result 0 whatever sum T*I is) -- stream padding, digital silence.
+// The exact stages then need not form the cross term at all.
+__device__ __forceinline__ bool ccoeff_ignores_corr(double wS1, double wU, const TemplStats& ts, int M) {
+    if (ts.flat) return true;
+    double diff2 = wU - wS1 * wS1 * (1.0 / (double)M);
+    diff2 = diff2 > 0.0 ? diff2 : 0.0;
+    double lim = 10.0 * (double)FLT_EPSILON * wU;
+    lim = lim < 0.5 ? lim : 0.5;
+    return diff2 <= lim;
+}
+
 // Score of one position from the cross term of the CENTRED samples xc = x - centre (what the direct MFMA
 // kernel accumulates) and the float64 prefix sums (w1, w2: the destination stream's, offset to the window):
 // sum T*I = sum T'I' + centre * (sum T + sum I) - centre^2 * M.  Returns the float32 cv2 would store at result[0][p].

@@ -341,7 +341,32 @@ void exact_tiles_kernel(TileParams a) {
         int mine = -1;                                                  // sparse: this thread's candidate, relative to p0
         if (!dense && tid < td.cnt) mine = a.cand[td.off + tid] - p0;
         double tot[XQ] = {0.0, 0.0, 0.0, 0.0};
-        for (int m0 = 0; m0 < M; m0 += XM) {
+        const TemplStats ts = templ_stats(a.r.src_s1, a.r.src_s2, sd.tmpl_off, M, a.r.centre);
+        const double* __restrict__ w1 = a.r.dst_s1 + sd.win_start;
+        const double* __restrict__ w2 = a.r.dst_s2 + sd.win_start;
+        const bool ccoeff = a.method == SUSHI_HIP_METHOD_CCOEFF_NORMED;
+        // TM_CCOEFF_NORMED: where cv2 takes the window for flat (stream padding, digital silence) its result is 0 whatever the
+        // cross term is -- which the float64 prefix sums alone decide.  A tile whose every position is like that needs no sums
+        // at all (such tiles are why a search that touches the padding is flagged in the first place).
+        bool needs_corr = true;
+        if (ccoeff) {
+            int need = 0;
+            if (quarter) {
+                const int p = p0 + tid;
+                need = p >= 0 && p < sd.n_pos && !ccoeff_ignores_corr(w1[p + M] - w1[p], w2[p + M] - w2[p], ts, M);
+            } else if (dense) {
+#pragma unroll
+                for (int q = 0; q < XQ; ++q) {
+                    const int p = p0 + XQ * tid + q;
+                    need |= p >= 0 && p < sd.n_pos && !ccoeff_ignores_corr(w1[p + M] - w1[p], w2[p + M] - w2[p], ts, M);
+                }
+            } else if (mine >= 0) {
+                const int p = p0 + mine;
+                need = !ccoeff_ignores_corr(w1[p + M] - w1[p], w2[p + M] - w2[p], ts, M);
+            }
+            needs_corr = __syncthreads_or(need) != 0;
+        }
+        for (int m0 = 0; needs_corr && m0 < M; m0 += XM) {
             const int mc = min(XM, M - m0);
             __syncthreads();                                            // previous chunk's (or tile's) reads are done
             for (int e = tid; e < XM; e += 256) lt[e] = e < mc ? (double)Tp[m0 + e] : 0.0;      // zero padded: whole steps of 4
@@ -381,16 +406,22 @@ void exact_tiles_kernel(TileParams a) {
 #pragma unroll
                 for (int q = 0; q < XQ; ++q) tot[q] += acc[q];
             } else if (mine >= 0) {
+                // (eight LDS reads of each operand in flight per step: one read, one multiply-add at a time, a listed candidate
+                // took as long as a whole dense tile -- three sparse tiles were the 2.6 ms of a run with two flagged searches)
                 const double* __restrict__ wv = li + mine;
                 double acc = 0.0;
-                for (int m = 0; m < mc; ++m) acc = __builtin_fma(lt[m], wv[m], acc);
+                int m = 0;
+                for (; m + 8 <= mc; m += 8) {
+                    double tv[8], wq[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { tv[j] = lt[m + j]; wq[j] = wv[m + j]; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc = __builtin_fma(tv[j], wq[j], acc);
+                }
+                for (; m < mc; ++m) acc = __builtin_fma(lt[m], wv[m], acc);
                 tot[0] += acc;
             }
         }
-        const TemplStats ts = templ_stats(a.r.src_s1, a.r.src_s2, sd.tmpl_off, M, a.r.centre);
-        const double* __restrict__ w1 = a.r.dst_s1 + sd.win_start;
-        const double* __restrict__ w2 = a.r.dst_s2 + sd.win_start;
-        const bool ccoeff = a.method == SUSHI_HIP_METHOD_CCOEFF_NORMED;
         auto key_at = [&](const double corr_u, const int p) {
             return ccoeff ? make_key_max(finish_ccoeff_normed(corr_u, w1[p + M] - w1[p], w2[p + M] - w2[p], ts, M), (unsigned)p)
                           : make_key(score_exact(corr_u, ts, w2, (int64_t)p, M), (unsigned)p);

@@ -7,7 +7,7 @@ export SUSHI_BENCH_CACHE=/tmp/sushi_bench_cache
 IFS='|' read -ra W <<< "$WL"
 for w in "${W[@]}"; do
   name=${w%%:*}; args=${w#*:}
-  B="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --cpu-sample 2 $args"
+  B="python bench.py --steps 5 --warmup 1 --profile-only $args"
   timeout 300 $B > $O/warm_$name.json 2> $O/warm_$name.err
   rm -rf gpurun_out/prof_kt
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -o kt -- $B > $O/kt_$name.log 2>&1
