@@ -53,3 +53,24 @@ def test_bench_default_workload_is_the_north_star_configuration():
     assert (c["events"], c["minutes"], c["window"], c["rate"]) == (3000, 120.0, 120.0, 12000)
     import inspect
     assert 'default=2' in inspect.getsource(bench.main)
+
+
+def test_pmc_traffic_of_every_bench_workload_is_current():
+    """profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, tools/gpu_final_r4.sh) holds an entry for the default
+    workload -- and for the other lines DESIGN.md quotes -- taken on THESE kernel sources: bench.py reports roofline.traffic
+    only while the digest matches, so a kernel edit without new counter passes shows up here, not as a silent null."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        entries = json.load(f)
+    digest = bench.kernel_source_digest()
+    for key in ("config2/fft/float32/3000/w120/m120/n1", "config2/fft/uint8/3000/w120/m120/n1",
+                "config2/fft/float32/3000/w120/m120/n1/hard0.05/off7.25", "config2/fft/float32/3000/w120/m120/n1/ccoeff_normed",
+                "config1/fft/float32/1000/w60/m45/n1", "config4/fft/float32/5000/w120/m240/n1"):
+        e = entries[key]
+        assert e["kernel_source_digest"] == digest, (key, e["kernel_source_digest"], digest)
+        k = e["kernels"]["mac_kernel"]
+        assert k["fetch_bytes"] > 0 and k["write_bytes"] > 0 and k["write_source"] == "WRITE_SIZE"
+        assert e["kernels"]["bound_kernel"]["fetch_bytes"] > 0
