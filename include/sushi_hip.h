@@ -175,6 +175,14 @@ SUSHI_HIP_API int sushi_hip_batch_info(const SushiHipBatch* batch, SushiHipBatch
  * SUSHI_HIP_METHOD_CCOEFF_NORMED: out_idx = first index of the MAXIMUM of cv2.matchTemplate(..., TM_CCOEFF_NORMED),
  * out_score = that float32. */
 SUSHI_HIP_API int sushi_hip_batch_set_method(SushiHipBatch* batch, int method);
+/* FFT path: whether block pairs are excluded by a lower bound of their scores before they are transformed.
+ * Results are the same either way; what differs is time.  AUTO (default after create): a sub-batch uses the exclusion when it has
+ * enough pairs for the bound pass and its extra launches to pay (more than 3000 + 2 x its searches: one find_substream call
+ * over a small window is a dozen pairs and a dozen launches -- 0.17 ms without, 0.23 with); ALWAYS / NEVER: for tests and measurements. */
+#define SUSHI_HIP_EXCLUDE_AUTO 0
+#define SUSHI_HIP_EXCLUDE_ALWAYS 1
+#define SUSHI_HIP_EXCLUDE_NEVER 2
+SUSHI_HIP_API int sushi_hip_batch_set_exclusion(SushiHipBatch* batch, int mode);
 /* One pass of the hot path over the batch (asynchronous):
  *   out_idx_dev[n]   = result.argmin(axis=1)[0]        (wav.py:186)
  *   out_score_dev[n] = result[0][min_idx], float32     (wav.py:188)

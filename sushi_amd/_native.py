@@ -26,6 +26,7 @@ NSTAGES = 6
 STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish", "bound")
 STAGE_KERNELS = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "ifft_kernel", "refine": "refine_kernel",
                  "finish": "collect_kernel+exact_tiles_kernel+unpack_keys_kernel", "bound": "bound_kernel"}
+EXCLUSION = {"auto": 0, "always": 1, "never": 2}        # SUSHI_HIP_EXCLUDE_*
 # every kernel a stage's HIP-event span covers (profiles/pmc_traffic.json is keyed by kernel)
 STAGE_KERNEL_SETS = {"tspec": ("tspec_kernel",), "mac": ("mac_kernel", "mac_long_kernel"),
                      "ifft": ("ifft_kernel", "pilot_kernel", "survivor_kernel"), "refine": ("refine_kernel",),
@@ -113,6 +114,8 @@ def lib():
     L.sushi_hip_batch_run.argtypes = [vp, dbl, vp, vp, vp]
     L.sushi_hip_batch_diagnostics.restype = ci
     L.sushi_hip_batch_diagnostics.argtypes = [vp, ctypes.POINTER(BatchDiag), vp, vp]
+    L.sushi_hip_batch_set_exclusion.restype = ci
+    L.sushi_hip_batch_set_exclusion.argtypes = [vp, ci]
     L.sushi_hip_batch_pair_bounds.restype = ci
     L.sushi_hip_batch_pair_bounds.argtypes = [vp, vp, vp, ctypes.POINTER(i64)]
     L.sushi_hip_batch_destroy.restype = None

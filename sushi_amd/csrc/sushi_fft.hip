@@ -1687,8 +1687,9 @@ size_t resolve_ws(const std::vector<SearchDesc>& descs, size_t cap) {
 struct SushiHipBatch {
     const SushiHipStream* dst;
     const SushiHipStream* src;
-    int n, path, variant, method;
+    int n, path, variant, method, exclusion;
     int64_t n_tiles;
+    int64_t direct_pairs;               // pairs of the last run's sub-batches that were transformed without the exclusion
     std::vector<SearchDesc> descs;
     Plan plan;
     BatchLayout lay;
@@ -1772,6 +1773,7 @@ int sushi_hip_batch_create(const SushiHipStream* dst, const SushiHipStream* src,
     if (!b) return SUSHI_HIP_EINVAL;
     std::unique_ptr<SushiHipBatch> guard(b);                     // freed on every early return and on an exception
     b->dst = dst; b->src = src; b->n = n; b->path = path; b->variant = variant; b->method = SUSHI_HIP_METHOD_SQDIFF_NORMED;
+    b->exclusion = SUSHI_HIP_EXCLUDE_AUTO;
     b->mem = (char*)mem_dev; b->last_stream = nullptr; b->ran = false; b->uploaded = nullptr;
     int rc = make_descs(req_host, n, variant, b->descs, &b->n_tiles);
     double flops = 0.0, abytes = 0.0;
@@ -1834,6 +1836,12 @@ int sushi_hip_batch_set_method(SushiHipBatch* b, int method) {
     return SUSHI_HIP_OK;
 }
 
+int sushi_hip_batch_set_exclusion(SushiHipBatch* b, int mode) {
+    if (!b || mode < SUSHI_HIP_EXCLUDE_AUTO || mode > SUSHI_HIP_EXCLUDE_NEVER) return SUSHI_HIP_EINVAL;
+    b->exclusion = mode;
+    return SUSHI_HIP_OK;
+}
+
 int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, float* out_score_dev, void* hip_stream) try {
     if (!b || !out_idx_dev || !out_score_dev) return SUSHI_HIP_EINVAL;
     hipStream_t st = (hipStream_t)hip_stream;
@@ -1847,7 +1855,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
     r.dst_raw = dst->raw; r.src_raw = src->raw; r.dtype = dst->dtype;
     const SearchDesc* searches_dev = (const SearchDesc*)(b->mem + b->lay.desc);
     unsigned long long* keys = (unsigned long long*)(b->mem + b->lay.keys);
-    b->last_stream = st; b->ran = true;
+    b->last_stream = st; b->ran = true; b->direct_pairs = 0;
     if (hipStreamWaitEvent(st, b->uploaded, 0) != hipSuccess) return SUSHI_HIP_ELAUNCH;   // descriptors and plan have landed
     if (b->path == SUSHI_HIP_PATH_DIRECT)
         return launch_direct(r, searches_dev, n_search, (int)b->n_tiles, b->variant, b->method, keys, out_idx_dev,
@@ -1925,16 +1933,24 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         ia.usrel = dst->usrel; ia.sbase = dst->base + (dst->blocks + 1);
         ia.flags = flags; ia.flag_list = flag_list; ia.sub_flagged = sub_flagged; ia.tiles = tiles; ia.candbuf = candbuf;
         ia.cand_cap = (int)cand_capacity(sbt.pairs); ia.counters = counters;
-        {
+        const bool ccm = b->method == SUSHI_HIP_METHOD_CCOEFF_NORMED;
+        auto launch_ifft = [&](const IfftArgs& x, unsigned grid) {
+            if (ccm) hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3(grid), dim3(FT), 0, st, x);
+            else hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3(grid), dim3(FT), 0, st, x);
+            return launch_ok();
+        };
+        // The exclusion costs a pass over Y (~16 ns per pair) and half a dozen launches (~60 us); transforming a pair ~37 ns:
+        // it pays from ~3000 pairs on, plus two per search (the pairs transformed first are transformed either way).
+        const bool exclude = b->exclusion == SUSHI_HIP_EXCLUDE_ALWAYS ||
+                             (b->exclusion == SUSHI_HIP_EXCLUDE_AUTO && sbt.pairs > 3000 + 2 * (int64_t)n_sub);
+        if (!exclude) {
+            // every pair, in the L2-friendly schedule (what round 3 did for every batch)
+            if (launch_ifft(ia, (unsigned)sbt.pairs) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            b->direct_pairs += sbt.pairs;
+        } else {
             // A lower bound of every pair's scores first (three of the transform's four passes, no scoring); then the most
             // promising pair of every search, which leaves the search's threshold; then whatever the bound could not exclude
             // (header of bound_kernel)
-            const bool ccm = b->method == SUSHI_HIP_METHOD_CCOEFF_NORMED;
-            auto launch_ifft = [&](const IfftArgs& x, unsigned grid) {
-                if (ccm) hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3(grid), dim3(FT), 0, st, x);
-                else hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3(grid), dim3(FT), 0, st, x);
-                return launch_ok();
-            };
             BoundArgs ba;
             memset(&ba, 0, sizeof(ba));
             ba.y = (const uint2*)y; ba.dst_stats = dst->stats; ba.searches = searches_dev + sbt.a0; ba.sub_first_pair = sbt.first_pair;
@@ -2018,7 +2034,7 @@ int sushi_hip_batch_diagnostics(SushiHipBatch* b, SushiHipBatchDiag* diag, float
     memcpy(&diag->max_bound_ratio, &c.max_ratio_bits, sizeof(float));
     memcpy(&diag->max_bound_ratio_noncandidate, &c.max_ratio_audit_bits, sizeof(float));
     diag->audited = (int64_t)c.audited;
-    diag->pairs_transformed = (int64_t)c.pairs_transformed;
+    diag->pairs_transformed = (int64_t)c.pairs_transformed + b->direct_pairs;
     std::vector<int32_t> fl((size_t)b->n);
     if (hipMemcpy(fl.data(), b->mem + b->lay.flags, (size_t)b->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
         return SUSHI_HIP_ELAUNCH;

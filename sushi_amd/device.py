@@ -177,10 +177,14 @@ class SearchBatch(object):
 
     method = 'sqdiff_normed' (default; cv2.TM_SQDIFF_NORMED + argmin, what wav.py:185-186 does) or 'ccoeff_normed'
     (cv2.TM_CCOEFF_NORMED + argmax, the method BASELINE.json's wording names); both on either path.
+
+    exclusion (FFT path) = 'auto' (default: the library excludes block pairs by a lower bound of their scores where a
+    sub-batch is large enough for that to pay), 'always', 'never' -- same results, different time; None reads
+    SUSHI_HIP_EXCLUSION (the GPU test suite sets it to 'always' so that every edge case goes through the exclusion).
     """
 
     def __init__(self, dst, src, tmpl_off, tmpl_len, win_start, n_pos, variant=None, path=None,
-                 delta=DEFAULT_DELTA, workspace_bytes=None, method="sqdiff_normed"):
+                 delta=DEFAULT_DELTA, workspace_bytes=None, method="sqdiff_normed", exclusion=None):
         self._handle = None
         if method not in _native.METHODS:
             raise SushiError("method must be one of %s" % sorted(_native.METHODS))
@@ -233,6 +237,12 @@ class SearchBatch(object):
             _native.check(rc, "sushi_hip_batch_create")
             self._handle = h
             _native.check(L.sushi_hip_batch_set_method(h, _native.METHODS[method]), "sushi_hip_batch_set_method")
+            if exclusion is None:
+                exclusion = os.environ.get("SUSHI_HIP_EXCLUSION", "auto")
+            if exclusion not in _native.EXCLUSION:
+                raise SushiError("exclusion must be one of %s" % sorted(_native.EXCLUSION))
+            self.exclusion = exclusion
+            _native.check(L.sushi_hip_batch_set_exclusion(h, _native.EXCLUSION[exclusion]), "sushi_hip_batch_set_exclusion")
             self.out_idx = torch.empty(n, dtype=torch.int32, device=dev)
             self.out_score = torch.empty(n, dtype=torch.float32, device=dev)
         info = _native.BatchInfo()

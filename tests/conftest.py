@@ -8,6 +8,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# Small batches skip the FFT path's pair exclusion by default (it does not pay below a few thousand pairs); the GPU tests are
+# small batches built to hit edge cases, and every one of them should go through the exclusion: they run with 'always' unless
+# a test asks otherwise (tests/test_pair_exclusion.py compares the modes).
+os.environ.setdefault("SUSHI_HIP_EXCLUSION", "always")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 

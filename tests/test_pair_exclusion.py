@@ -22,9 +22,9 @@ def _stream(n, seed, lowpass=8):
     return y.astype(np.float32)
 
 
-def _run(dst, src, offs, lens, wst, npos, method="sqdiff_normed"):
+def _run(dst, src, offs, lens, wst, npos, method="sqdiff_normed", exclusion="always"):
     from sushi_amd.device import DeviceStream, SearchBatch
-    b = SearchBatch(DeviceStream(dst), DeviceStream(src), offs, lens, wst, npos, path="fft", method=method)
+    b = SearchBatch(DeviceStream(dst), DeviceStream(src), offs, lens, wst, npos, path="fft", method=method, exclusion=exclusion)
     b.run()
     idx, score = b.results()
     return idx, score, b
@@ -139,3 +139,30 @@ def test_coarse_prefix_table():
         s2, s1 = d.s2.cpu().numpy(), d.s1.cpu().numpy()
         e = np.minimum(np.arange(nc) * 256, n)
         assert (c[:nc] == s2[e]).all() and (c[nc:] == s1[e]).all()
+
+
+@pytest.mark.parametrize("method", ["sqdiff_normed", "ccoeff_normed"])
+@pytest.mark.parametrize("dtype", [np.float32, np.uint8])
+def test_always_never_and_auto_give_the_same_results(method, dtype):
+    """The exclusion only ever decides what is NOT looked at: index and float32 score bits are the same with it, without it, and
+    with the library choosing (a small batch like this one: without)."""
+    n = 20 * PAIR
+    dst = _stream(n, 11)
+    rng = np.random.default_rng(12)
+    src = (dst + rng.standard_normal(n).astype(np.float32) * 0.03).clip(0, 1).astype(np.float32)
+    if dtype == np.uint8:
+        dst, src = (dst * 255).astype(np.uint8), (src * 255).astype(np.uint8)
+    offs, lens, wst, npos = [], [], [], []
+    for k in range(10):
+        m = int(rng.integers(600, 40000))
+        a = int(rng.integers(3 * PAIR, n - 3 * PAIR - m))
+        ws = a - int(rng.integers(0, 2 * PAIR))
+        offs.append(a); lens.append(m); wst.append(ws); npos.append(min(int(rng.integers(PAIR // 2, 6 * PAIR)), n - ws - m + 1))
+    res = {}
+    for mode in ("always", "never", "auto"):
+        idx, score, b = _run(dst, src, offs, lens, wst, npos, method, exclusion=mode)
+        res[mode] = (idx.copy(), score.copy().view(np.uint32), b.diagnostics()["pairs_transformed"], b.fft_pairs)
+    assert (res["always"][0] == res["never"][0]).all() and (res["always"][1] == res["never"][1]).all()
+    assert (res["auto"][0] == res["never"][0]).all() and (res["auto"][1] == res["never"][1]).all()
+    assert res["never"][2] == res["never"][3] == res["auto"][2]          # no exclusion: every pair transformed; auto = never at this size
+    assert res["always"][2] < res["never"][2]
