@@ -299,7 +299,8 @@ class SearchBatch(object):
 
     def pair_bounds(self):
         """FFT path, after run(): (slb float32[pairs], acc float32[pairs, 2]) of the last sub-batch -- every block pair's lower
-        bound of its scores (-inf: none) and what it was made from (sushi_hip_batch_pair_bounds).  Synchronises."""
+        bound of its scores (-inf: none) and what it was made from (sushi_hip_batch_pair_bounds).  Only meaningful when that
+        sub-batch went through the exclusion (exclusion='always', or 'auto' on a large batch).  Synchronises."""
         n = ctypes.c_int64(int(self.fft_pairs))
         slb = np.empty(int(self.fft_pairs), np.float32)
         acc = np.empty((int(self.fft_pairs), 2), np.float32)
