@@ -1,0 +1,14 @@
+#!/bin/bash
+# Builds (here, on the CPU box: hipcc cross-compiles) the variant libraries tools/gpu_r5_first_call.sh times.  They start from HEAD.
+set -e
+cd "$(dirname "$0")/../.."
+E=tools/experiments
+python tools/build_variant.py sw            --patch $E/r05_mac_store_wave.patch
+python tools/build_variant.py iso_no_wait   --patch $E/r05_mac_store_wave.patch --patch $E/r05_store_wave_iso_no_wait_on_top.patch
+python tools/build_variant.py iso_no_wait_no_store --patch $E/r05_mac_store_wave.patch --patch $E/r05_store_wave_iso_no_wait_no_store_on_top.patch
+python tools/build_variant.py iso_no_consumer --patch $E/r05_mac_store_wave.patch --patch $E/r05_store_wave_iso_no_consumer_on_top.patch
+python tools/build_variant.py iso_w5        --patch $E/r05_iso_product_idle_fifth_wave.patch
+python tools/build_variant.py iso_w5_2cu    --patch $E/r05_iso_product_idle_fifth_wave_two_per_cu.patch
+python tools/build_variant.py no_y          --patch $E/r05_mac_ablation_no_y.patch
+python tools/build_variant.py la2           --patch $E/r06_mac_class12_24_rows.patch
+ls -la sushi_amd/lib/
