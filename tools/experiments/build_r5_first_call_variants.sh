@@ -11,4 +11,6 @@ python tools/build_variant.py iso_w5        --patch $E/r05_iso_product_idle_fift
 python tools/build_variant.py iso_w5_2cu    --patch $E/r05_iso_product_idle_fifth_wave_two_per_cu.patch
 python tools/build_variant.py no_y          --patch $E/r05_mac_ablation_no_y.patch
 python tools/build_variant.py la2           --patch $E/r06_mac_class12_24_rows.patch
+python tools/build_variant.py bound2        --patch $E/r06_bound_two_passes.patch
+python tools/build_variant.py bound2_la2    --patch $E/r06_bound_two_passes.patch --patch $E/r06_mac_class12_24_rows.patch
 ls -la sushi_amd/lib/

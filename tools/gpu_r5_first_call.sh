@@ -1,7 +1,8 @@
-# Next round's first GPU call (about 3 GPU-minutes): where do the 12.8 ms of the store-wave variant's compute waves go?
+# Next round's first GPU call (about 5 GPU-minutes): where do the 12.8 ms of the store-wave variant's compute waves go?
 # Build the libraries first, here: tools/experiments/build_r5_first_call_variants.sh.  Then
 #   gpurun --timeout 400 -- 'bash tools/gpu_r5_first_call.sh'
-# CORRECT results: product, la2, sw, iso_w5, iso_w5_2cu  (bench.py: parity sample + stage times)
+# CORRECT results: product, la2, bound2, bound2_la2 (the two prepared gains: adopt what holds, then tools/gpu_final_r4.sh), sw, iso_w5, iso_w5_2cu
+#   (bench.py: parity sample + stage times; bound2: also tests/test_pair_exclusion.py + tests/test_gpu_parity.py under it)
 # GARBAGE Y (timing only, 13 s of exact fall-back per step: stage_times.py --steps 1): no_y, iso_no_wait, iso_no_wait_no_store, iso_no_consumer
 #   iso_w5                 product + an idle fifth wave                        -> what 320-thread workgroups cost by themselves
 #   iso_w5_2cu             ... + the queue's 30 KB of LDS                      -> ... at two workgroups per CU
@@ -14,11 +15,14 @@ O=gpurun_out/${OUT:-r5_first}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export SUSHI_BENCH_CACHE=/tmp/sushi_bench_cache
-for V in product la2 sw iso_w5 iso_w5_2cu; do
+for V in product la2 bound2 bound2_la2 sw iso_w5 iso_w5_2cu; do
   if [ $V = product ]; then unset SUSHI_HIP_LIB; else export SUSHI_HIP_LIB=$PWD/sushi_amd/lib/libsushi_hip_$V.so; fi
   [ $V = product ] || [ -f "$SUSHI_HIP_LIB" ] || { echo "$V: not built" | tee -a $O/notes.txt; continue; }
   timeout 60 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --cpu-sample 64 > $O/bench_$V.json 2> $O/b_$V.err; tail -n 2 $O/b_$V.err
 done
+if [ -f $PWD/sushi_amd/lib/libsushi_hip_bound2_la2.so ]; then
+  SUSHI_HIP_LIB=$PWD/sushi_amd/lib/libsushi_hip_bound2_la2.so timeout 400 python -m pytest tests/test_pair_exclusion.py tests/test_gpu_parity.py tests/test_ccoeff.py -m gpu -q -x > $O/pytest_bound2_la2.log 2>&1; tail -n 4 $O/pytest_bound2_la2.log
+fi
 for V in no_y iso_no_consumer iso_no_wait_no_store iso_no_wait; do
   export SUSHI_HIP_LIB=$PWD/sushi_amd/lib/libsushi_hip_$V.so
   [ -f "$SUSHI_HIP_LIB" ] || { echo "$V: not built" | tee -a $O/notes.txt; continue; }
@@ -27,7 +31,7 @@ done
 unset SUSHI_HIP_LIB
 python - <<PY
 import json
-for V in "product la2 sw iso_w5 iso_w5_2cu".split():
+for V in "product la2 bound2 bound2_la2 sw iso_w5 iso_w5_2cu".split():
     try:
         d=json.load(open("$O/bench_%s.json" % V)); r=d["roofline"]; p=d["parity"]
         print(V, round(d["value"]), round(d["ms_per_step"],2), {k: round(v,3) for k,v in r["stage_ms"].items()}, r["diagnostics"]["flagged"], p["oracle_sample_searches"], p.get("max_idx_err_vs_oracle_sample"))
