@@ -13,4 +13,7 @@ python tools/build_variant.py no_y          --patch $E/r05_mac_ablation_no_y.pat
 python tools/build_variant.py la2           --patch $E/r06_mac_class12_24_rows.patch
 python tools/build_variant.py bound2        --patch $E/r06_bound_two_passes.patch
 python tools/build_variant.py bound2_la2    --patch $E/r06_bound_two_passes.patch --patch $E/r06_mac_class12_24_rows.patch
+python tools/build_variant.py probe_sw      --patch $E/r05_mac_store_wave.patch --patch $E/r05_store_wave_probe_on_top.patch
+python tools/build_variant.py probe_product --patch $E/r05_product_probe.patch
+python tools/build_variant.py probe_no_y    --patch $E/r05_mac_ablation_no_y.patch --patch $E/r05_product_probe.patch
 ls -la sushi_amd/lib/

@@ -28,6 +28,12 @@ for V in no_y iso_no_consumer iso_no_wait_no_store iso_no_wait; do
   [ -f "$SUSHI_HIP_LIB" ] || { echo "$V: not built" | tee -a $O/notes.txt; continue; }
   timeout 60 python tools/stage_times.py --steps 1 --tag $V 2>$O/st_$V.err | tail -n 1 | tee -a $O/garbage_timing.jsonl
 done
+# per-wave timing records of one launch (tools/read_mac_probe.py): where a producer wave's time goes (probe_no_y: garbage Y, one 13 s run)
+for V in probe_product probe_sw probe_no_y; do
+  export SUSHI_HIP_LIB=$PWD/sushi_amd/lib/libsushi_hip_$V.so
+  [ -f "$SUSHI_HIP_LIB" ] || continue
+  timeout 60 python tools/read_mac_probe.py --tag $V 2>$O/probe_$V.err | tail -n 1 | tee -a $O/mac_probe.jsonl
+done
 unset SUSHI_HIP_LIB
 python - <<PY
 import json
