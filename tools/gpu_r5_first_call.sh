@@ -1,6 +1,6 @@
 # Next round's first GPU call (about 7 GPU-minutes; drop the pytest block to save 2.5): where do the 12.8 ms of the store-wave variant's compute waves go?
 # Build the libraries first, here: tools/experiments/build_r5_first_call_variants.sh.  Then
-#   gpurun --timeout 400 -- 'bash tools/gpu_r5_first_call.sh'
+#   gpurun --timeout 600 -- 'bash tools/gpu_r5_first_call.sh'
 # CORRECT results: product, la2, bound2, bound2_la2 (the two prepared gains: adopt what holds, then tools/gpu_final_r4.sh), sw, iso_w5, iso_w5_2cu
 #   (bench.py: parity sample + stage times; bound2: also tests/test_pair_exclusion.py + tests/test_gpu_parity.py under it)
 # GARBAGE Y (timing only, 13 s of exact fall-back per step: stage_times.py --steps 1): no_y, iso_no_wait, iso_no_wait_no_store, iso_no_consumer
