@@ -4,6 +4,7 @@ set -e
 cd "$(dirname "$0")/../.."
 E=tools/experiments
 python tools/build_variant.py sw            --patch $E/r05_mac_store_wave.patch
+python tools/build_variant.py sw2           --patch $E/r05_mac_store_wave.patch --patch $E/r05_store_wave_two_groups_on_top.patch
 python tools/build_variant.py iso_no_wait   --patch $E/r05_mac_store_wave.patch --patch $E/r05_store_wave_iso_no_wait_on_top.patch
 python tools/build_variant.py iso_no_wait_no_store --patch $E/r05_mac_store_wave.patch --patch $E/r05_store_wave_iso_no_wait_no_store_on_top.patch
 python tools/build_variant.py iso_no_consumer --patch $E/r05_mac_store_wave.patch --patch $E/r05_store_wave_iso_no_consumer_on_top.patch

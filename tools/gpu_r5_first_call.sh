@@ -10,12 +10,15 @@
 #   iso_no_wait_no_store   ... store wave polls and frees the slots, no stores -> the store wave's presence
 #   iso_no_wait            ... and stores                                      -> the stores from a fifth wave
 #   sw                     the whole design                                    -> + the reserve wait
+#   sw2                    ... two (4 + 1)-wave groups per workgroup             -> is it the PLACEMENT of five-wave workgroups?  At 164 VGPRs a SIMD
+#                          holds three waves; two five-wave workgroups fit a CU only if they double up on different SIMDs, and the
+#                          counters of the one-group build say 7 resident waves per CU on average, not 10 (SQ_WAVE_CYCLES over the kernel's time)
 set -x
 O=gpurun_out/${OUT:-r5_first}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export SUSHI_BENCH_CACHE=/tmp/sushi_bench_cache
-for V in product la2 bound2 bound2_la2 sw iso_w5 iso_w5_2cu; do
+for V in product la2 bound2 bound2_la2 sw sw2 iso_w5 iso_w5_2cu; do
   if [ $V = product ]; then unset SUSHI_HIP_LIB; else export SUSHI_HIP_LIB=$PWD/sushi_amd/lib/libsushi_hip_$V.so; fi
   [ $V = product ] || [ -f "$SUSHI_HIP_LIB" ] || { echo "$V: not built" | tee -a $O/notes.txt; continue; }
   timeout 60 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --cpu-sample 64 > $O/bench_$V.json 2> $O/b_$V.err; tail -n 2 $O/b_$V.err
@@ -37,7 +40,7 @@ done
 unset SUSHI_HIP_LIB
 python - <<PY
 import json
-for V in "product la2 bound2 bound2_la2 sw iso_w5 iso_w5_2cu".split():
+for V in "product la2 bound2 bound2_la2 sw sw2 iso_w5 iso_w5_2cu".split():
     try:
         d=json.load(open("$O/bench_%s.json" % V)); r=d["roofline"]; p=d["parity"]
         print(V, round(d["value"]), round(d["ms_per_step"],2), {k: round(v,3) for k,v in r["stage_ms"].items()}, r["diagnostics"]["flagged"], p["oracle_sample_searches"], p.get("max_idx_err_vs_oracle_sample"))
