@@ -5,6 +5,11 @@ cd "$(dirname "$0")/../.."
 E=tools/experiments
 python tools/build_variant.py sw            --patch $E/r05_mac_store_wave.patch
 python tools/build_variant.py sw2           --patch $E/r05_mac_store_wave.patch --patch $E/r05_store_wave_two_groups_on_top.patch
+SW2="--patch $E/r05_mac_store_wave.patch --patch $E/r05_store_wave_two_groups_on_top.patch"
+python tools/build_variant.py sw2_q8        $SW2 --patch $E/r05_sw2_queue8_on_top.patch
+python tools/build_variant.py sw2_q8_r4     $SW2 --patch $E/r05_sw2_queue8_rounds_of_four_on_top.patch
+python tools/build_variant.py sw2_m3        $SW2 --patch $E/r05_sw2_drain3_on_top.patch
+python tools/build_variant.py sw2_no_wait   $SW2 --patch $E/r05_sw2_no_wait_on_top.patch
 python tools/build_variant.py iso_no_wait   --patch $E/r05_mac_store_wave.patch --patch $E/r05_store_wave_iso_no_wait_on_top.patch
 python tools/build_variant.py iso_no_wait_no_store --patch $E/r05_mac_store_wave.patch --patch $E/r05_store_wave_iso_no_wait_no_store_on_top.patch
 python tools/build_variant.py iso_no_consumer --patch $E/r05_mac_store_wave.patch --patch $E/r05_store_wave_iso_no_consumer_on_top.patch
