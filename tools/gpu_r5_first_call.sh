@@ -1,9 +1,9 @@
-# Next round's first GPU call (about 7 GPU-minutes; drop the pytest block to save 2.5): where do the 12.8 ms of the store-wave variant's compute waves go?
+# Next round's first GPU call (about 6 GPU-minutes; drop the pytest block to save 2.5): where do the 12.8 ms of the store-wave variant's compute waves go?
 # Build the libraries first, here: tools/experiments/build_r5_first_call_variants.sh.  Then
 #   gpurun --timeout 600 -- 'bash tools/gpu_r5_first_call.sh'
 # CORRECT results: product, la2, bound2, bound2_la2 (the two prepared gains: adopt what holds, then tools/gpu_final_r4.sh), sw, iso_w5, iso_w5_2cu
 #   (bench.py: parity sample + stage times; bound2: also tests/test_pair_exclusion.py + tests/test_gpu_parity.py under it)
-# GARBAGE Y (timing only, 13 s of exact fall-back per step: stage_times.py --steps 1): no_y, iso_no_wait, iso_no_wait_no_store, iso_no_consumer
+# GARBAGE Y (timing only; built with r05_timing_only_on_top.patch, which skips everything behind mac_kernel: stage_times.py --steps 5): no_y, iso_no_wait, iso_no_wait_no_store, iso_no_consumer
 #   iso_w5                 product + an idle fifth wave                        -> what 320-thread workgroups cost by themselves
 #   iso_w5_2cu             ... + the queue's 30 KB of LDS                      -> ... at two workgroups per CU
 #   iso_no_consumer        queue pushes, no reserve wait, store wave returns   -> the pushes alone (compare with no_y: 1.7 ms)
@@ -32,7 +32,7 @@ fi
 for V in no_y sw2_no_wait iso_no_consumer iso_no_wait_no_store iso_no_wait; do
   export SUSHI_HIP_LIB=$PWD/sushi_amd/lib/libsushi_hip_$V.so
   [ -f "$SUSHI_HIP_LIB" ] || { echo "$V: not built" | tee -a $O/notes.txt; continue; }
-  timeout 60 python tools/stage_times.py --steps 1 --tag $V 2>$O/st_$V.err | tail -n 1 | tee -a $O/garbage_timing.jsonl
+  timeout 60 python tools/stage_times.py --steps 5 --tag $V 2>$O/st_$V.err | tail -n 1 | tee -a $O/garbage_timing.jsonl
 done
 # per-wave timing records of one launch (tools/read_mac_probe.py): where a producer wave's time goes (probe_no_y: garbage Y, one 13 s run)
 for V in probe_product probe_sw probe_no_y; do
