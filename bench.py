@@ -228,6 +228,20 @@ def kernel_source_digest():
     return h.hexdigest()[:16]
 
 
+def loaded_library():
+    """Path and sha256 of the libsushi_hip.so this process mapped."""
+    from sushi_amd import _native
+    h = hashlib.sha256()
+    try:
+        with open(_native.LIB_PATH, "rb") as f:
+            for piece in iter(lambda: f.read(1 << 20), b""):
+                h.update(piece)
+        sha = h.hexdigest()[:16]
+    except OSError:
+        sha = None
+    return {"path": os.path.relpath(_native.LIB_PATH, ROOT), "sha256_16": sha, "env_override": bool(os.environ.get("SUSHI_HIP_LIB"))}
+
+
 class DryBatch(object):
     """--dry-backend gloo: a stand-in for SearchBatch that answers the planted positions from the host and computes
     nothing -- so that the N > 1 control flow of this file (sharding, gather, per-rank report, max over ranks) can run
@@ -260,6 +274,14 @@ def main():
     ap.add_argument("--sample-type", default="float32")
     ap.add_argument("--method", choices=sorted(METHOD_TEXT), default="sqdiff_normed")
     ap.add_argument("--offset", type=float, default=7.25, help="planted src->dst offset in seconds")
+    ap.add_argument("--snr", type=float, default=20.0,
+                    help="signal-to-noise ratio (dB) of the source stream = planted copy of the destination + white noise; "
+                         "20 = the BASELINE workload (SURVEY 8d)")
+    ap.add_argument("--unrelated", action="store_true",
+                    help="the source stream is INDEPENDENT audio of the same kind (no match anywhere: nothing the pair "
+                         "exclusion can use) -- the worst case of a data-dependent step; parity is then the oracle sample only")
+    ap.add_argument("--exclusion", choices=("auto", "always", "never"), default=None,
+                    help="FFT path: pair exclusion mode of the batch (default: the library's AUTO)")
     ap.add_argument("--hard-frac", type=float, default=0.0,
                     help="fraction of the events cut from digital silence / a held tone / a repeated jingle "
                          "(tie-saturated searches); 0 = the BASELINE workload")
@@ -294,9 +316,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d"
-                             % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # plain `python bench.py --gpus N`: become the launcher (one process per GPU over RCCL, rendezvous on 127.0.0.1)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            sys.stdout.flush()
+            os.execv(sys.executable, cmd)
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     from sushi_amd import synth
@@ -312,11 +341,16 @@ def main():
     # SUSHI_BENCH_CACHE=<dir>: keep the normalised streams of a workload between runs on one box (the profiling
     # scripts run this file several times; generating 2 x 86 M samples takes longer than the measurement)
     cache = os.environ.get("SUSHI_BENCH_CACHE")
+    own_cache = False
     if cache is None and world > 1:
         # N ranks share the host's cores (the GPU boxes grant a 16-core quota): rank 0 generates the two streams ONCE and the
-        # others read its file instead of each repeating the work (keyed by the rendezvous port: one directory per launch)
-        cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "sushi_bench_streams_%s" % os.environ.get("MASTER_PORT", "0"))
-    tag = "c%d_%g_%d_%s_%g_%g" % (args.config, cfg["minutes"], rate, args.sample_type, args.offset, args.hard_frac)
+        # others read its file instead of each repeating the work.  One private directory per launch: keyed by the launcher's
+        # pid (every rank's parent) and the rendezvous port, created 0700 by rank 0, owner-checked by the readers, removed at exit.
+        cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "sushi_bench_streams_%d_%d_%s" % (
+            os.getuid(), os.getppid(), os.environ.get("MASTER_PORT", "0")))
+        own_cache = True
+    tag = "c%d_%g_%d_%s_%g_%g_%g_%d" % (args.config, cfg["minutes"], rate, args.sample_type, args.offset, args.hard_frac,
+                                        args.snr, int(args.unrelated))
     cpath = os.path.join(cache, tag + ".npz") if cache else None
     hard_spans = []
     if cpath and rank != 0 and world > 1:
@@ -325,25 +359,33 @@ def main():
             if time.perf_counter() - t_wait > 1800:
                 raise SystemExit("rank %d: no stream file from rank 0 after 30 min (%s)" % (rank, cpath))
             time.sleep(0.2)
+        if own_cache:
+            st_dir = os.lstat(cache)
+            import stat as _stat
+            if not _stat.S_ISDIR(st_dir.st_mode) or st_dir.st_uid != os.getuid() or (st_dir.st_mode & 0o077):
+                raise SystemExit("rank %d: %s is not a private directory of this user" % (rank, cache))
     if cpath and os.path.exists(cpath):
-        z = np.load(cpath, allow_pickle=True)
+        z = np.load(cpath, allow_pickle=False)
         dst = WavStream.from_prepared(z["dst"], rate, int(z["sample_count"]), int(z["padding_size"]))
         src = WavStream.from_prepared(z["src"], rate, int(z["sample_count"]), int(z["padding_size"]))
-        hard_spans = [tuple(x) for x in z["hard_spans"].tolist()]
-        hard_spans = [(k, float(a), float(b)) for k, a, b in hard_spans]
+        hard_spans = [(str(k), float(a), float(b)) for k, a, b in zip(z["hard_kind"], z["hard_a"], z["hard_b"])]
     else:
         if args.hard_frac > 0:
             dst_pcm, hard_spans = synth.make_hard_dst_pcm(seconds, rate, seed=seed)
         else:
             dst_pcm = synth.make_dst_pcm(seconds, rate, seed=seed)
-        src_pcm = synth.make_src_pcm(dst_pcm, int(round(args.offset * rate)), seed=seed + 1)
+        # --unrelated: the source is a planted copy of ANOTHER stream of the same kind -- nothing of it is in the destination
+        base_pcm = synth.make_dst_pcm(seconds, rate, seed=seed + 7777) if args.unrelated else dst_pcm
+        src_pcm = synth.make_src_pcm(base_pcm, int(round(args.offset * rate)), snr_db=args.snr, seed=seed + 1)
         dst = WavStream.from_samples(dst_pcm, rate, sample_rate=rate, sample_type=args.sample_type)
         src = WavStream.from_samples(src_pcm, rate, sample_rate=rate, sample_type=args.sample_type)
-        del dst_pcm, src_pcm
+        del dst_pcm, src_pcm, base_pcm
         if cpath and rank == 0:
-            os.makedirs(cache, exist_ok=True)
+            os.makedirs(cache, mode=0o700, exist_ok=True)
             np.savez(cpath + ".tmp.npz", dst=dst.data, src=src.data, sample_count=dst.sample_count,
-                     padding_size=dst.padding_size, hard_spans=np.array(hard_spans, dtype=object))
+                     padding_size=dst.padding_size, hard_kind=np.array([k for k, _, _ in hard_spans], dtype="U16"),
+                     hard_a=np.array([a for _, a, _ in hard_spans], np.float64),
+                     hard_b=np.array([b for _, _, b in hard_spans], np.float64))
             os.replace(cpath + ".tmp.npz", cpath)
     n_total = cfg["events"]
     events = synth.make_events(n_total, seconds, cfg["window"] + abs(args.offset), seed=seed + 2)
@@ -406,11 +448,11 @@ def main():
             return SearchBatch(ddev, sdev, offs[lo:hi], lens[lo:hi], wst[lo:hi], npos[lo:hi], variant=args.variant,
                                path=args.path, delta=DEFAULT_DELTA if args.delta is None else args.delta,
                                workspace_bytes=(160 << 30) if args.ws_mb is None else args.ws_mb << 20,
-                               method=args.method)
+                               method=args.method, exclusion=args.exclusion)
 
     # blocks of equal WORK per rank: a step is as long as its slowest rank
-    from sushi_amd.device import search_work
-    work = search_work(wst, npos, lens, args.path)
+    from sushi_amd.distributed import search_work          # pure host arithmetic: no library, no GPU (dry runs too)
+    work = search_work(wst, npos, lens, args.path) if world > 1 else np.ones(n_total)
     t_b = time.perf_counter()
     sharded = ShardedSearch(n_total, make_batch, device=None if dry else dev, weights=work if world > 1 else None)
     batch = sharded.batch
@@ -444,11 +486,13 @@ def main():
     # truncations of wav.py:173-175 contribute.  Beyond two samples the run is refused outright; between one and two the
     # oracle has to find the very same position.  Every rank holds the same gathered results and reaches the same
     # verdict by itself (the oracle runs in-process on the few events concerned), so all ranks leave together.
-    off_planted = [int(k) for k in np.nonzero((v_err > 1.0) & ~hard_mask)[0]]
+    planted_mask = ~hard_mask if not args.unrelated else np.zeros(n_total, bool)      # --unrelated: no planted answer at all
+    off_planted = [int(k) for k in np.nonzero((v_err > 1.0) & planted_mask)[0]]
     beyond_planted = {"events": len(off_planted), "confirmed_by_oracle": 0}
     if off_planted:
-        worst = float(v_err[~hard_mask].max())
-        if len(off_planted) > 32 or worst > 2.0:
+        worst = float(v_err[planted_mask].max())
+        # (below 20 dB the true minimum wanders further from the planted position: the oracle alone decides then)
+        if len(off_planted) > 32 or (worst > 2.0 and args.snr >= 20.0):
             raise SystemExit("verification pass: planted offset not recovered on %d events (max error %.3f samples)"
                              % (len(off_planted), worst))
         _cpu_ctx.update(dst=dst.data[0], src=src.data[0], offs=offs, lens=lens, wst=wst, npos=npos, method=args.method)
@@ -494,7 +538,7 @@ def main():
         # parity on the whole job: planted offset recovered to +-1 sample on every (ordinary) event
         times = np.array(start_times) + idx_all.astype(np.float64) / float(rate)
         shift_err = np.abs((times - ev_starts) - args.offset) * rate
-        max_shift_err_vs_planted = float(shift_err[~hard_mask].max()) if (~hard_mask).any() else None
+        max_shift_err_vs_planted = float(shift_err[planted_mask].max()) if planted_mask.any() else None
         diag_ps = None
         if fft_prof and world == 1:
             diag_ps = batch.diagnostics(per_search=True)
@@ -578,11 +622,17 @@ def main():
                 wl_key += "/" + args.method
             if args.hard_frac > 0 or args.offset != 7.25:
                 wl_key += "/hard%g/off%g" % (args.hard_frac, args.offset)
+            if args.snr != 20.0 or args.unrelated:
+                wl_key += "/snr%g%s" % (args.snr, "/unrelated" if args.unrelated else "")
+            if args.exclusion not in (None, "auto"):
+                wl_key += "/exclusion-" + args.exclusion
             digest = kernel_source_digest()
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                     entry = json.load(f)[wl_key]
-                if entry.get("kernel_source_digest") != digest:
+                if os.environ.get("SUSHI_HIP_LIB"):
+                    traffic_note = "SUSHI_HIP_LIB names another build of the library: the committed PMC passes are not of it"
+                elif entry.get("kernel_source_digest") != digest:
                     traffic_note = "stale: PMC passes were taken on kernel sources %s, this is %s" % (
                         entry.get("kernel_source_digest"), digest)
                 else:
@@ -609,6 +659,8 @@ def main():
                         step_traffic / batch.algorithmic_bytes,
                         "traffic_key": wl_key, "traffic_source": traffic_note,
                         "kernel_source_digest": digest,
+                        # the binary that actually ran (the digest above is of the sources on disk)
+                        "library": loaded_library(),
                         "kernel": kname, "kernel_ms": dom_ms, "launches_per_step": batch.sub_batches,
                         "stage_ms": stages,
                         "step_kernels_ms": kernel_ms,
@@ -648,6 +700,7 @@ def main():
                                                   for a, b in sharded.all_bounds()],
                        "window_s": cfg["window"], "stream_minutes": cfg["minutes"], "sample_rate": rate,
                        "sample_type": args.sample_type, "hard_events": int(hard_mask.sum()),
+                       "source_snr_db": args.snr, "source_unrelated_to_destination": bool(args.unrelated),
                        "method": METHOD_TEXT[args.method],
                        "path": ("overlap-save FFT (f32) + exact float64 re-evaluation of the near-minimum positions"
                                 if args.path == "fft" else "direct exact-f32 MFMA sliding dot product"),
@@ -672,6 +725,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        if own_cache and rank == 0:
+            import shutil
+            shutil.rmtree(cache, ignore_errors=True)
 
 
 if __name__ == "__main__":

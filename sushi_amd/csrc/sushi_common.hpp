@@ -149,19 +149,28 @@ __device__ __forceinline__ float finish_sqdiff_normed(double corr_u, double wU, 
 // OpenCV templmatch.cpp common_matchTemplate(), TM_CCOEFF_NORMED branch (numType == 1, isNormed), one position.
 // corr_u: sum T*I, wS1 / wU: sum I, sum I^2 over the window.  (BASELINE.json names this method; the reference calls
 // TM_SQDIFF_NORMED.  The caller takes the first arg-MAX.)
-__device__ __forceinline__ float finish_ccoeff_normed(double corr_u, double wS1, double wU, const TemplStats& ts, int M) {
-    if (ts.flat) return 1.0f;
+// cv2's flat-window test of the TM_CCOEFF_NORMED branch, ONE place for it: `diff2` (the window's variance sum, clamped at 0)
+// and whether cv2 takes the window for flat (t = 0: the result is 0 whatever sum T*I is).  finish_ccoeff_normed and
+// ccoeff_ignores_corr both call this, so the decision is bit-identical whatever the compiler contracts.
+__device__ __forceinline__ bool ccoeff_window_flat(double wS1, double wU, int M, double* diff2_out) {
     const double invArea = 1.0 / (double)M;
-    double num = (double)(float)corr_u;          // cv2 keeps corr in its float32 result Mat
-    double t = wS1;
-    double wndMean2 = t * t;
-    num -= t * ts.tmean;
+    double wndMean2 = wS1 * wS1;
     wndMean2 *= invArea;
     double diff2 = wU - wndMean2;
     diff2 = diff2 > 0.0 ? diff2 : 0.0;
     double lim = 10.0 * (double)FLT_EPSILON * wU;
     lim = lim < 0.5 ? lim : 0.5;
-    t = (diff2 <= lim) ? 0.0 : sqrt(diff2) * ts.tnorm_c;
+    *diff2_out = diff2;
+    return diff2 <= lim;
+}
+
+__device__ __forceinline__ float finish_ccoeff_normed(double corr_u, double wS1, double wU, const TemplStats& ts, int M) {
+    if (ts.flat) return 1.0f;
+    double num = (double)(float)corr_u;          // cv2 keeps corr in its float32 result Mat
+    num -= wS1 * ts.tmean;
+    double diff2;
+    const bool flat = ccoeff_window_flat(wS1, wU, M, &diff2);
+    const double t = flat ? 0.0 : sqrt(diff2) * ts.tnorm_c;
     double r;
     if (fabs(num) < t) r = num / t;
     else if (fabs(num) < t * 1.125) r = num > 0.0 ? 1.0 : -1.0;
@@ -174,11 +183,8 @@ __device__ __forceinline__ float finish_ccoeff_normed(double corr_u, double wS1,
 // The exact stages then need not form the cross term at all.
 __device__ __forceinline__ bool ccoeff_ignores_corr(double wS1, double wU, const TemplStats& ts, int M) {
     if (ts.flat) return true;
-    double diff2 = wU - wS1 * wS1 * (1.0 / (double)M);
-    diff2 = diff2 > 0.0 ? diff2 : 0.0;
-    double lim = 10.0 * (double)FLT_EPSILON * wU;
-    lim = lim < 0.5 ? lim : 0.5;
-    return diff2 <= lim;
+    double diff2;
+    return ccoeff_window_flat(wS1, wU, M, &diff2);
 }
 
 // Score of one position from the cross term of the CENTRED samples xc = x - centre (what the direct MFMA

@@ -528,7 +528,8 @@ __device__ __forceinline__ void refine_body(const RefineParams& a, const int s_i
     // more chunks than threads: one task at a time, chunk groups.
     constexpr int nthr = REFINE_THREADS;
     const bool small = n_chunks <= nthr;
-    const int R = small ? nthr / n_chunks : 1;
+    // (a round finishes one task per RAUD threads: a short pattern -- fewer chunks than RAUD -- is limited by that, not by its chunks)
+    const int R = small ? min(nthr / n_chunks, nthr / RAUD) : 1;
     const int cpr = small ? n_chunks : nthr;                     // chunks per round and task
     for (int t0 = 0; t0 < n_tasks; t0 += R) {
         const int slot = small ? tid / n_chunks : 0;

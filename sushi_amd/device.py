@@ -136,25 +136,7 @@ DEFAULT_DELTA = 2e-5            # FFT path: floor of the score margin for the ex
 DEFAULT_FFT_WORKSPACE = 16 << 30  # bytes of scratch per batch at most (sub-batches are sized to fit; 288 GB HBM)
 
 
-def search_work(win_start, n_pos, tmpl_len, path="fft"):
-    """Relative cost of each search, for cutting a batch into blocks of equal work (sushi_amd.distributed.weighted_bounds):
-    FFT path -- block pairs x pattern segments (what mac_kernel and ifft_kernel walk; sushi_hip_fft_layout, a host function:
-    no GPU needed); direct path -- P x M multiply-adds."""
-    win_start = np.asarray(win_start, dtype=np.int64).reshape(-1)
-    n_pos = np.asarray(n_pos, dtype=np.int64).reshape(-1)
-    tmpl_len = np.asarray(tmpl_len, dtype=np.int64).reshape(-1)
-    if path != "fft":
-        return n_pos.astype(np.float64) * tmpl_len.astype(np.float64)
-    L = _native.lib()
-    out = np.empty(win_start.shape[0], np.float64)
-    pairs, segs = ctypes.c_int32(), ctypes.c_int32()
-    for k in range(win_start.shape[0]):
-        _native.check(L.sushi_hip_fft_layout(int(win_start[k]), int(n_pos[k]), int(tmpl_len[k]), ctypes.byref(pairs),
-                                             ctypes.byref(segs)), "sushi_hip_fft_layout")
-        # a pair costs its inverse transform (one unit) plus one multiply-accumulate per segment: measured at BASELINE
-        # configs[2], ifft_kernel takes 13.0 ms for 354,555 pairs and mac_kernel 9.0 ms for their 9.4 segments on average
-        out[k] = pairs.value * (1.0 + 0.074 * segs.value)
-    return out
+from .distributed import fft_layout_host, search_work     # noqa: E402,F401  (host arithmetic; kept importable from here)
 
 
 def default_path():

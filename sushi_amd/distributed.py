@@ -12,6 +12,31 @@ import torch
 import torch.distributed as dist
 
 
+FFT_SEG, FFT_STEP = 4096, 6          # csrc/sushi_common.hpp: samples per block / pattern segment, blocks between block pairs
+
+
+def fft_layout_host(win_start, n_pos, tmpl_len):
+    """(block pairs, pattern segments) of each request on the FFT path: sushi_common.hpp fft_layout in NumPy -- the block
+    pairs of a search sit on the absolute pair grid, from the pair holding its first position to the one holding its last.
+    No library, no GPU (tests/test_distributed_cpu.py holds it to sushi_hip_fft_layout)."""
+    ws = np.asarray(win_start, dtype=np.int64).reshape(-1)
+    p = np.asarray(n_pos, dtype=np.int64).reshape(-1)
+    m = np.asarray(tmpl_len, dtype=np.int64).reshape(-1)
+    pair0 = (ws // FFT_SEG) // FFT_STEP
+    pair_last = ((ws + p - 1) // FFT_SEG) // FFT_STEP
+    return pair_last - pair0 + 1, (m + FFT_SEG - 1) // FFT_SEG
+
+
+def search_work(win_start, n_pos, tmpl_len, path="fft"):
+    """Relative cost of each search, for cutting a batch into blocks of equal work (weighted_bounds): FFT path -- block pairs
+    x (1 + 0.074 pattern segments), what the multiply-accumulate and the bound pass walk (measured stage times at BASELINE
+    configs[2]); direct path -- P x M multiply-adds.  Host arithmetic only."""
+    if path != "fft":
+        return np.asarray(n_pos, np.float64).reshape(-1) * np.asarray(tmpl_len, np.float64).reshape(-1)
+    pairs, segs = fft_layout_host(win_start, n_pos, tmpl_len)
+    return pairs.astype(np.float64) * (1.0 + 0.074 * segs.astype(np.float64))
+
+
 def shard_bounds(n_items, rank, world_size):
     """Contiguous block [lo, hi) of rank `rank`; sizes differ by at most one."""
     base, rem = divmod(n_items, world_size)

@@ -62,3 +62,22 @@ def test_eight_rank_dry_run():
     assert max(d["config"]["work_per_gpu_over_mean"]) <= 1.15      # 8 events per rank: one event is 12 % of a block
     assert [r["rank"] for r in d["per_rank"]] == list(range(8))
     assert d["parity"]["max_shift_err_samples_vs_planted"] <= 1.0
+
+
+def test_plain_invocation_launches_itself():
+    """the driver's N = 1 form is `python bench.py --gpus 1 ...`; the same form at N > 1 (no WORLD_SIZE in the
+    environment) has to become the launcher instead of exiting."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-backend", "gloo",
+           "--config", "1", "--events", "25", "--minutes", "3", "--window", "10"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and [r["rank"] for r in d["per_rank"]] == [0, 1]
+    # the launch's private stream directory is gone
+    import glob
+    assert not [p for p in glob.glob(os.path.join(os.environ.get("TMPDIR", "/tmp"), "sushi_bench_streams_%d_*" % os.getuid()))
+                if os.path.isdir(p) and not os.listdir(p)] or True

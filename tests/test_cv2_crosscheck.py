@@ -1,13 +1,16 @@
 """Cross-check against the call the reference actually makes (wav.py:185: cv2.matchTemplate), wherever cv2 imports.
 
-It does not in the build image (no OpenCV, no network: SURVEY F4) -- these tests then SKIP and parity stays
-"unpinned at the cv2 boundary" (DESIGN.md section 5).  On any machine with OpenCV they run by themselves and turn the
-oracle's restatement -- and, with a GPU, the HIP path -- into a comparison with the real thing.
+It does not in the build image nor on the GPU boxes (no OpenCV, no network: SURVEY F4; profiles/r05/cv2_probe.txt records
+every route that was tried) -- these tests then SKIP and parity stays "unpinned at the cv2 boundary" (DESIGN.md section 5).
+On any machine with OpenCV they run by themselves and turn the oracle's restatement -- and, with a GPU, the HIP path --
+into a comparison with the real thing.
 
-Tolerance: BASELINE.json's (shift within +-1 sample, score within 1e-4 relative), plus the float32 quantum of cv2's
-stored cross term (2.5e-7 absolute).  cv2's crossCorr runs its block DFT in float32 for CV_8U and CV_32F input, so real
-cv2 output carries ~1e-6 * corr of noise that neither the oracle (exactly rounded corr) nor the HIP path models: equal
-indices are demanded only where the oracle's own row separates the best two positions by more than that noise.
+PRIMARY assertion: BASELINE.json's gate as it stands -- shift within +-1 sample, score within 1e-4 relative plus the
+float32 quantum of cv2's stored cross term (2.5e-7 absolute).  cv2's crossCorr runs its block DFT in float64 for CV_32F
+input and in FLOAT32 for CV_8U input (oracle.py cross_correlate_cv2_model): for uint8 streams the real call carries
+~1e-6 * corr of DFT noise that the oracle (exactly rounded corr) does not model, so the uint8 cases additionally REPORT
+their excess over the gate (`UINT8_DFT_SLACK`, a second, looser number that only they may use) instead of hiding it in
+the gate itself.
 """
 import numpy as np
 import pytest
@@ -15,6 +18,19 @@ import pytest
 cv2 = pytest.importorskip("cv2")
 
 RTOL, ATOL = 1e-4, 2.5e-7
+UINT8_DFT_SLACK = 2e-6          # cv2's float32 DFT on CV_8U input (module docstring): uint8 cases only, and reported when used
+TIE_SLACK = {np.dtype(np.float32): 2.5e-7, np.dtype(np.uint8): 4e-6}
+
+
+def _gate(value, ref, dtype, what):
+    """The strict gate; uint8 cases may exceed it by cv2's own float32-DFT noise, which is printed when it happens."""
+    err = abs(float(value) - float(ref))
+    strict = RTOL * abs(float(ref)) + ATOL
+    if err <= strict:
+        return
+    assert np.dtype(dtype) == np.uint8, (what, err, strict)
+    assert err <= strict + UINT8_DFT_SLACK, (what, err, strict)
+    print("uint8 case over BASELINE's gate by %.3g (x%.2f): cv2's float32 DFT, %s" % (err - strict, err / strict, what))
 
 
 def _cases():
@@ -34,12 +50,12 @@ def _cases():
     return out
 
 
-def _agree(row_a, row_b, method):
+def _agree(row_a, row_b, method, dtype):
     pick = np.argmin if method == "sqdiff_normed" else np.argmax
     ia, ib = int(pick(row_a)), int(pick(row_b))
-    assert abs(float(row_a[ia]) - float(row_b[ib])) <= RTOL * abs(float(row_b[ib])) + ATOL + 2e-6
-    if ia != ib:                      # acceptable only as a tie inside cv2's own float32-DFT noise
-        assert abs(float(row_b[ia]) - float(row_b[ib])) <= 4e-6, (ia, ib)
+    _gate(row_a[ia], row_b[ib], dtype, "best score")
+    if ia != ib:                      # acceptable only as a tie inside the quantum of cv2's own stored result
+        assert abs(float(row_b[ia]) - float(row_b[ib])) <= TIE_SLACK[np.dtype(dtype)], (ia, ib)
     return ia, ib
 
 
@@ -50,8 +66,9 @@ def test_oracle_restatement_equals_cv2(oracle, method):
         ref = oracle.match_template_cv2(dst, src, method)[0]
         ours = oracle.match_template(dst, src, method=method)[0]
         assert ref.shape == ours.shape
-        assert np.abs(ours.astype(np.float64) - ref).max() <= RTOL + 4e-6, np.abs(ours - ref).max()
-        ia, ib = _agree(ours, ref, method)
+        worst = int(np.abs(ours.astype(np.float64) - ref).argmax())
+        _gate(ours[worst], ref[worst], dst.dtype, "whole row, worst position")
+        ia, ib = _agree(ours, ref, method, dst.dtype)
         assert abs(ia - planted) <= 1 and abs(ib - planted) <= 1
 
 
@@ -70,6 +87,6 @@ def test_hip_path_equals_cv2(oracle, method, path):
         pick = np.argmin if method == "sqdiff_normed" else np.argmax
         ib = int(pick(ref))
         assert abs(int(idx[0]) - ib) <= 1
-        assert abs(float(score[0]) - float(ref[ib])) <= RTOL * abs(float(ref[ib])) + ATOL + 2e-6
+        _gate(score[0], ref[ib], dst.dtype, "HIP %s path" % path)
         if int(idx[0]) != ib:
-            assert abs(float(ref[int(idx[0])]) - float(ref[ib])) <= 4e-6
+            assert abs(float(ref[int(idx[0])]) - float(ref[ib])) <= TIE_SLACK[np.dtype(dst.dtype)]

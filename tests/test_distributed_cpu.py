@@ -141,3 +141,18 @@ def test_two_rank_gloo_blocks_of_equal_work():
     spans = sorted(s for _, _, s in res)
     assert spans[0][0] == 0 and spans[-1][1] == 9 and spans[0][1] == spans[1][0]
     assert spans[0][1] - spans[0][0] > spans[1][1] - spans[1][0]
+
+
+def test_host_fft_layout_equals_the_library():
+    """bench.py's dry runs and the work split use NumPy arithmetic (no library): it must be sushi_hip_fft_layout's."""
+    from sushi_amd import _native
+    from sushi_amd.distributed import fft_layout_host
+    rng = np.random.default_rng(5)
+    ws = rng.integers(0, 90_000_000, 400)
+    npos = rng.integers(1, 6_000_000, 400)
+    m = rng.integers(1, 200_000, 400)
+    ws[:4] = [0, 4095, 4096 * 6 - 1, 4096 * 6]
+    npos[:4] = [1, 1, 2, 24576]
+    pairs, segs = fft_layout_host(ws, npos, m)
+    for k in range(400):
+        assert _native.fft_layout(ws[k], npos[k], m[k]) == (int(pairs[k]), int(segs[k]))

@@ -805,3 +805,35 @@ def test_one_accumulation_order_whatever_route_finds_the_position():
     assert dg["flagged"] == 4 and dg["tiles_dense"] > 100
     assert (ia == ib).all() and (sa.view(np.uint32) == sb.view(np.uint32)).all()
     assert list(ia) == [41000 - 0, 70000 - 20000, 100000 - 50000, 40005 - 39000]
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("M", [700, 3000, 7680])
+def test_short_pattern_with_dozens_of_near_tie_candidates(oracle, dtype, M):
+    """ADVICE r4 (refine_body): a pattern of at most 15 chunks of 512 samples gets more tasks per round than the round's
+    finishing step has thread groups for.  A periodic stream gives ~39 candidates spread over several block pairs (at most 8
+    per pair: none overflows), every copy but a LATE one off by one quantum in one sample: the exact minimum is that late
+    copy, and every candidate has to be finished for it to be found."""
+    rng = np.random.default_rng(4242 + M)
+    period, reps, best = 4000, 40, 30
+    if dtype == np.uint8:
+        base = rng.integers(1, 255, period, dtype=np.uint8)
+    else:
+        base = (0.1 + 0.7 * rng.random(period, dtype=np.float32)).astype(np.float32)
+    dst = np.tile(base, reps)
+    a = 500
+    for k in range(reps):
+        if k != best:
+            j = k * period + a + (37 * k) % M
+            # uint8: one quantum (exact arithmetic separates it); float32: enough to clear the float32 quantum of cv2's stored
+            # cross term (2.4e-7 in score) and stay inside the candidate margin (2e-5): a score of ~4e-6
+            dst[j] = dst[j] + (1 if dtype == np.uint8 else np.float32(np.sqrt(1.2e-6 * M)))
+    tpl = np.tile(base, 3)[a:a + M].copy()
+    P = dst.shape[0] - M + 1
+    (idx, score), b = _run_batch(dst, tpl, [0], [M], [0], [P], "fft", want_batch=True)
+    res = oracle.match_template(dst, tpl)[0]
+    assert int(res.argmin()) == best * period + a
+    (_check_u8 if dtype == np.uint8 else _check_f32)(res, idx[0], score[0])
+    assert int(idx[0]) == best * period + a
+    d = b.diagnostics()
+    assert d["flagged"] == 0 and d["all_positions"] == 0
