@@ -280,8 +280,8 @@ def main():
     ap.add_argument("--unrelated", action="store_true",
                     help="the source stream is INDEPENDENT audio of the same kind (no match anywhere: nothing the pair "
                          "exclusion can use) -- the worst case of a data-dependent step; parity is then the oracle sample only")
-    ap.add_argument("--exclusion", choices=("auto", "always", "never"), default=None,
-                    help="FFT path: pair exclusion mode of the batch (default: the library's AUTO)")
+    ap.add_argument("--exclusion", choices=("auto", "always", "never", "band", "whole"), default=None,
+                    help="FFT path: pair exclusion mode of the batch (default: the library's AUTO; band / whole force one form)")
     ap.add_argument("--hard-frac", type=float, default=0.0,
                     help="fraction of the events cut from digital silence / a held tone / a repeated jingle "
                          "(tie-saturated searches); 0 = the BASELINE workload")

@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define SUSHI_HIP_ABI_VERSION 9   /* 9: SushiHipBatchDiag.audited / .pairs_transformed, SUSHI_HIP_STAGE_BOUND, (urel, srel) interleaved */
+#define SUSHI_HIP_ABI_VERSION 10  /* 10: band-split exclusion (low-band rows + row norms behind the spectra, SUSHI_HIP_EXCLUDE_BAND / _WHOLE,
+                                     SushiHipBatchDiag.excluded_audited / .max_slb_ratio_excluded / .slb_violations / .band / .band_votes) */
 
 #if defined(__GNUC__)
 #define SUSHI_HIP_API __attribute__((visibility("default")))
@@ -82,7 +83,10 @@ SUSHI_HIP_API int sushi_hip_device_ok(void);
  *                  (x - mean)[jB .. jB+N) + i * (x - mean)[jB+H .. jB+H+N)         (zeros past the end)
  *              as packed halves (float16 re, float16 im: 4 bytes per bin) times one power of two per stream, bin f at
  *              sushi_hip_fft_slot_of_bin(f), followed by one all-zero block:
- *              sushi_hip_stream_spectra_bytes(n) = (nb + 1) * N * 4 bytes.
+ *              (nb + 1) * N * 4 bytes; behind them, for the band-split form of the pair exclusion:
+ *              the LOW BAND (bins f < N/8 and f >= 7N/8) of every block spectrum once more, (nb + 1) * N bytes, in the order
+ *              the bound's transform loads it, and float32[nb + 1]: the norm of each block spectrum's stored halves
+ *              OUTSIDE that band.  sushi_hip_stream_spectra_bytes(n) is the sum.
  * A stream that is only a source of patterns does not need spectra. */
 typedef struct SushiHipStream SushiHipStream;
 
@@ -108,6 +112,8 @@ SUSHI_HIP_API int sushi_hip_stream_add_spectra(SushiHipStream* stream, void* mem
 #define SUSHI_HIP_VIEW_BASE1 7    /* float64[nb+1] */
 #define SUSHI_HIP_VIEW_COARSE 8   /* float64[2][n / 256 + 2]: s2, then s1, at every 256th sample (entries past the end: the totals) --
                                     what the FFT path's lower bound of a block pair's window energies reads */
+#define SUSHI_HIP_VIEW_SPECTRA_LOW 9   /* the low-band rows behind the spectra (packed halves, N bytes per block) */
+#define SUSHI_HIP_VIEW_ZNORM_REST 10   /* float32[nb + 1]: norm of each block spectrum outside the band */
 SUSHI_HIP_API int sushi_hip_stream_view(const SushiHipStream* stream, int which, const void** ptr_dev, size_t* bytes);
 SUSHI_HIP_API void sushi_hip_stream_destroy(SushiHipStream* stream);
 
@@ -151,8 +157,18 @@ typedef struct SushiHipBatchDiag {
                                  all_positions too.  The bound is a statistical model (8 standard deviations of the packed-half
                                  roundings), not a worst-case proof: this field is what watches it. */
     int64_t audited;          /* audited non-candidate positions of the run */
-    int64_t pairs_transformed; /* FFT path, TM_SQDIFF_NORMED: block pairs whose inverse transform was run and scored; the other
-                                 info.fft_pairs - this were excluded by a lower bound of their scores (bound_kernel) */
+    int64_t pairs_transformed; /* FFT path: block pairs whose inverse transform was run and scored; the other
+                                 info.fft_pairs - this were excluded by a lower bound of their scores */
+    int64_t excluded_audited; /* of those: pairs the bound HAD excluded, transformed all the same -- per run one hashed pair of every
+                                 audited search (all of them by default), a different one every run -- so that the lower bound is held
+                                 to what such a pair really scores, not only to the pairs it let through */
+    float max_slb_ratio_excluded; /* max over the audited excluded pairs of (the pair's lower bound) / (an upper bound of the exact
+                                 score of its best position); < 1 or the search went to all_positions */
+    int32_t slb_violations;   /* transformed pairs (audited or not) whose lower bound was found above a real score: 0 */
+    int32_t band;             /* form of the exclusion the last run used: 0 whole rows, 1 band-split, -1 none */
+    int32_t band_votes[2];    /* what AUTO / ALWAYS decided the form from (first run of a batch): block pairs looked at, and those whose
+                                 bound -- with nothing but the rows' norms outside the band -- already leaves room to exclude; the
+                                 band-split form is taken when that is >= 90 % */
 } SushiHipBatchDiag;
 
 typedef struct SushiHipBatch SushiHipBatch;
@@ -182,6 +198,13 @@ SUSHI_HIP_API int sushi_hip_batch_set_method(SushiHipBatch* batch, int method);
 #define SUSHI_HIP_EXCLUDE_AUTO 0
 #define SUSHI_HIP_EXCLUDE_ALWAYS 1
 #define SUSHI_HIP_EXCLUDE_NEVER 2
+/* The exclusion has two forms with the same results.  WHOLE: the bound is taken from the products of whole spectra (every pair's
+ * 64 KB row written and read back once).  BAND: only the low band (|f| < N/8, a quarter of the bins) is multiplied, stored and
+ * transformed; what the other bins can add is bounded from the norms of the rows that meet (Cauchy-Schwarz), and whole rows are
+ * formed only for the few pairs that are transformed after all.  BAND needs streams that keep most of their energy in the band
+ * (audio does): AUTO and ALWAYS decide per batch, from the streams' own norms, which form to use; these two force one. */
+#define SUSHI_HIP_EXCLUDE_BAND 3
+#define SUSHI_HIP_EXCLUDE_WHOLE 4
 SUSHI_HIP_API int sushi_hip_batch_set_exclusion(SushiHipBatch* batch, int mode);
 /* One pass of the hot path over the batch (asynchronous):
  *   out_idx_dev[n]   = result.argmin(axis=1)[0]        (wav.py:186)

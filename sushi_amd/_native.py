@@ -19,18 +19,19 @@ U8, F32 = 0, 1
 PATH_FFT, PATH_DIRECT = 0, 1
 METHOD_SQDIFF_NORMED, METHOD_CCOEFF_NORMED = 0, 1       # cv2.TM_SQDIFF_NORMED + argmin (wav.py:185-186) | cv2.TM_CCOEFF_NORMED + argmax
 METHODS = {"sqdiff_normed": METHOD_SQDIFF_NORMED, "ccoeff_normed": METHOD_CCOEFF_NORMED}
-VIEW_XC, VIEW_S1, VIEW_S2, VIEW_UREL, VIEW_BASE, VIEW_SPECTRA, VIEW_USREL, VIEW_BASE1, VIEW_COARSE = range(9)
+VIEW_XC, VIEW_S1, VIEW_S2, VIEW_UREL, VIEW_BASE, VIEW_SPECTRA, VIEW_USREL, VIEW_BASE1, VIEW_COARSE, VIEW_SPECTRA_LOW, \
+    VIEW_ZNORM_REST = range(11)
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 NSTAGES = 6
 STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish", "bound")
-STAGE_KERNELS = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "ifft_kernel", "refine": "refine_kernel",
-                 "finish": "collect_kernel+exact_tiles_kernel+unpack_keys_kernel", "bound": "bound_kernel"}
-EXCLUSION = {"auto": 0, "always": 1, "never": 2}        # SUSHI_HIP_EXCLUDE_*
+STAGE_KERNELS = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "mac_list_kernel+ifft_kernel", "refine": "refine_kernel",
+                 "finish": "collect_kernel+exact_tiles_kernel+unpack_keys_kernel", "bound": "bound_low_kernel|bound_kernel"}
+EXCLUSION = {"auto": 0, "always": 1, "never": 2, "band": 3, "whole": 4}        # SUSHI_HIP_EXCLUDE_*
 # every kernel a stage's HIP-event span covers (profiles/pmc_traffic.json is keyed by kernel)
 STAGE_KERNEL_SETS = {"tspec": ("tspec_kernel",), "mac": ("mac_kernel", "mac_long_kernel"),
-                     "ifft": ("ifft_kernel", "pilot_kernel", "survivor_kernel"), "refine": ("refine_kernel",),
-                     "finish": ("collect_kernel", "exact_tiles_kernel"), "bound": ("bound_kernel", "slb_kernel")}
+                     "ifft": ("ifft_kernel", "pilot_kernel", "survivor_kernel", "mac_list_kernel"), "refine": ("refine_kernel",),
+                     "finish": ("collect_kernel", "exact_tiles_kernel"), "bound": ("bound_kernel", "bound_low_kernel", "slb_kernel")}
 
 # struct SushiHipRequest, 24 bytes
 REQUEST_DTYPE = np.dtype([("tmpl_off", "<i8"), ("win_start", "<i8"), ("tmpl_len", "<i4"), ("n_pos", "<i4")], align=True)
@@ -48,7 +49,9 @@ class BatchDiag(ctypes.Structure):
     _fields_ = [("flagged", ctypes.c_int32), ("all_positions", ctypes.c_int32), ("tiles_dense", ctypes.c_int64),
                 ("tiles_sparse", ctypes.c_int64), ("candidates", ctypes.c_int64), ("max_bound_ratio", ctypes.c_float),
                 ("max_bound_ratio_noncandidate", ctypes.c_float), ("audited", ctypes.c_int64),
-                ("pairs_transformed", ctypes.c_int64)]
+                ("pairs_transformed", ctypes.c_int64), ("excluded_audited", ctypes.c_int64),
+                ("max_slb_ratio_excluded", ctypes.c_float), ("slb_violations", ctypes.c_int32), ("band", ctypes.c_int32),
+                ("band_votes", ctypes.c_int32 * 2)]
 
 
 _lib = None

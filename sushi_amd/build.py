@@ -28,7 +28,7 @@ UNITS = [
     # register shuffles (v_mov / accvgpr traffic); plain v_fma_f32 already issues at the f32 peak rate.
     ("sushi_fft", ["-fno-slp-vectorize"],
      [os.path.join(CSRC, "fft_core.hpp"), os.path.join(CSRC, "mac_core.hpp"), TWIDDLE_INC, os.path.join(CSRC, "_gen_dft16_f16.inc"),
-      os.path.join(CSRC, "_gen_dft16_f16_bound.inc")]),
+      os.path.join(CSRC, "_gen_dft16_f16_bound.inc"), os.path.join(CSRC, "_gen_dft16_f16_bound_low.inc")]),
 ]
 
 
@@ -110,6 +110,34 @@ def write_dft16_bound_operands():
     return DFT16H_INC
 
 
+DFT16L_INC = os.path.join(CSRC, "_gen_dft16_f16_bound_low.inc")
+
+
+def write_dft16_bound_low_operands():
+    """The B operands of bound_low_kernel's first pass (fft_core.hpp fft_wave_half_front_low, dft16_low_operand): the rows of the
+    16-point inverse DFT matrix for the eight d1 a low-band group holds, high halves times 2^-10 -- [real parts of the result,
+    imaginary parts][lane] x 4 halves as two 32-bit words (K = 16: v_mfma_f32_16x16x16_f16)."""
+    import numpy as np
+    d1_of = lambda kq, j: kq + (0, 2, 12, 14)[j]
+    words = []
+    for form in (0, 1):
+        vals = np.empty((64, 4), np.float64)
+        for l in range(64):
+            for j in range(4):
+                kq, n = l >> 4, l & 15
+                part, d1 = kq >> 1, d1_of(kq & 1, j)
+                ang = 2.0 * math.pi * ((n * d1) & 15) / 16.0
+                wr, wi = math.cos(ang), math.sin(ang)
+                vals[l, j] = (wr if part == 0 else -wi) if form == 0 else (wi if part == 0 else wr)
+        words.append(np.ascontiguousarray((vals * 2.0 ** -10).astype(np.float16)).view(np.uint32).reshape(-1))
+    flat = np.concatenate(words)
+    text = "".join("0x%08xu,%s" % (int(v), "\n" if i % 8 == 7 else " ") for i, v in enumerate(flat))
+    if not os.path.exists(DFT16L_INC) or open(DFT16L_INC).read() != text:
+        with open(DFT16L_INC, "w") as f:
+            f.write(text)
+    return DFT16L_INC
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -119,7 +147,7 @@ def _stale(target, deps):
 
 def needs_build():
     if not os.path.exists(TWIDDLE_INC) or not os.path.exists(os.path.join(CSRC, "_gen_dft16_f16.inc")) or \
-            not os.path.exists(os.path.join(CSRC, "_gen_dft16_f16_bound.inc")):
+            not os.path.exists(os.path.join(CSRC, "_gen_dft16_f16_bound.inc")) or not os.path.exists(DFT16L_INC):
         return True
     deps = list(COMMON_DEPS)
     for name, _flags, extra in UNITS:
@@ -134,6 +162,7 @@ def build_native(force=False, verbose=False, defines=(), lib=None, obj_tag=""):
     write_twiddles()
     write_dft16_operands()
     write_dft16_bound_operands()
+    write_dft16_bound_low_operands()
     lib = lib or LIB
     if not force and not defines and not needs_build():
         return lib

@@ -679,5 +679,130 @@ __device__ __forceinline__ void fft_wave_half_front(const uint4v (&yl)[4], h2* v
 }
 #endif  // __HIPCC__
 
+// ------------------------------------------------------------------------------------------------------------
+// The LOW BAND of a spectrum (bins |f| < N/8: LB_BINS = N/4 of them) as its own transform -- bound_low_kernel.
+//
+// y_low(x) = sum over the band of Y(f) exp(2 pi i f x / N) is a trigonometric polynomial of degree n = N/8.  Sampled at
+// M = N/2 equidistant points x = 2 r' its modulus is everywhere at most 1 / cos(pi n / M) = sqrt(2) times the largest sample
+// (Ehlich & Zeller 1964; M. Riesz's lemma: a real trigonometric polynomial of degree n and maximum 1 at x* stays above
+// cos(n h) at x* + h, |h| <= pi / n -- and a node is never further than pi / M from x*; for complex values rotate the maximum onto
+// the real axis).  The samples are an N/2-point inverse transform of
+//     V[k] = Y(k) (k < N/8),  Y(k + N/2) (k >= 3N/8),  0 otherwise,
+// and, decimated by eight, y_low[2 r'] = sum_g w^(g r') A_g[r' mod 1024] with A_g the 1024-point inverse transform of
+// V_g[m] = V[g + 8 m] -- of whose 1024 inputs only m < 256 and m >= 768 exist.  So
+//     |y_low(x)| <= sqrt(2) * sum_g max_k |A_g[k]|        for EVERY x,
+// from eight half-empty 1024-point transforms per pair instead of the sixteen full ones of the whole spectrum: a sixth of
+// the instructions (pass 1 on v_mfma_f32_16x16x16_f16: only the eight non-zero d1 of sixteen enter), a quarter of the bytes.
+//
+// A group's transform has the digit structure of the wave plan above (m = 64 d1 + 4 d2 + d3, outputs k2 = e1 + 16 e2 + 256 e3,
+// the same twiddles): passes 2 and 3 are fft_wave_half_front's own.  Low rows are stored in the order THIS transform loads them:
+// the forward transforms end with thread tid holding X[tid + 1024 r] in register r, and the band is r = 0, 1, 14, 15 of every
+// thread -- V indices tid + {0, 1024, 6144, 7168}, all in group g = tid & 7, m = t + {0, 128, 768, 896} with t = tid >> 3,
+// i.e. d1 = (t >> 6) + {0, 2, 12, 14} of column (d2, d3) = ((t >> 2) & 15, t & 3): ONE 16-byte entry per forward thread.
+//   entry position in a low row:  ((g * 4 + g4) * 32 + 16 kq + m'),   kq = t >> 6, g4 = d2 >> 2, m' = (d3 << 2) | (d2 & 3)
+//   (group g's 2 KB are contiguous; lane l < 32 of the transforming wave loads entry (g * 4 + g4) * 32 + l for g4 = 0 .. 3)
+// A operand of v_mfma_f32_16x16x16_f16, lane (kq' = l >> 4, m' = l & 15): k = 4 kq' + j;  kq' = 0 / 1: real parts of the
+// entry with kq = 0 / 1 (d1 = kq + {0, 2, 12, 14}[j]), kq' = 2 / 3: their imaginary parts (one v_permlane32_swap hands them up).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int LB_HW = WN / 8;                  // the band: bins f < LB_HW and f >= WN - LB_HW
+constexpr int LB_BINS = 2 * LB_HW;
+constexpr int LB_ENTRIES = LB_BINS / 4;        // 16-byte entries of a low row
+constexpr int LB_GROUPS = 8;
+SUSHI_HHD int lslot_of_thread(int tid) {
+    const int g = tid & 7, t = tid >> 3;
+    const int kq = t >> 6, g4 = (t >> 4) & 3, mm = ((t & 3) << 2) | ((t >> 2) & 3);
+    return (g * 4 + g4) * 32 + 16 * kq + mm;
+}
+// the d1 digit of sub-position j of an entry with parity kq, and the V index / frequency bin it is
+SUSHI_HHD int lb_d1(int kq, int j) { return kq + (j == 0 ? 0 : (j == 1 ? 2 : (j == 2 ? 12 : 14))); }
+SUSHI_HHD int lb_bin_of(int entry, int j) {     // frequency bin (0 .. WN-1) of sub-position j of entry `entry` of a low row
+    const int g = entry >> 7, g4 = (entry >> 5) & 3, l = entry & 31, kq = l >> 4, mm = l & 15;
+    const int d2 = 4 * g4 + (mm & 3), d3 = mm >> 2;
+    const int m = 64 * lb_d1(kq, j) + 4 * d2 + d3;
+    const int k = g + 8 * m;                      // index on the N/2 grid
+    return k < WN / 8 ? k : k + WN / 2;
+}
+// B operands of the K = 16 first pass (inverse transform, times 2^-10; high halves only): element j of lane l is row
+// k = 4 (l >> 4) + j of column n = l & 15.  form 0: real parts of the result, 1: imaginary parts.
+SUSHI_HHD double dft16_low_operand(int form, int l, int j) {
+    const int kq = l >> 4, n = l & 15, part = kq >> 1, d1 = lb_d1(kq & 1, j);
+    const double PI = 3.14159265358979323846;
+    const double wr = __builtin_cos(2.0 * PI * (double)((n * d1) & 15) / 16.0), wi = __builtin_sin(2.0 * PI * (double)((n * d1) & 15) / 16.0);
+    return form == 0 ? (part == 0 ? wr : -wi) : (part == 0 ? wi : wr);
+}
+
+#ifdef __HIPCC__
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+struct MfmaBl { half4 r, i; };
+__device__ __forceinline__ MfmaBl load_mfma_bl(const int lane, const uint2v* __restrict__ table) {
+    MfmaBl b;
+    b.r = __builtin_bit_cast(half4, table[lane]);
+    b.i = __builtin_bit_cast(half4, table[64 + lane]);
+    return b;
+}
+// passes 2 and 3 of the packed-half front (shared by the whole-spectrum and the low-band transforms)
+__device__ __forceinline__ void fft_wave_half_tail(h2* v, const HTwiddles& tw) {
+#pragma unroll
+    for (int t = 1; t < 16; ++t) v[t] = h_cmul(v[t], tw.p2[t]);     // pass 2: twiddle w256^(e1 d2), then the DFTs over d2
+    DftH<16>::run(v);
+    auto swap32 = [](h2& x, h2& y) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+        unsigned ra = r[0], rb = r[1];
+        asm volatile("" : "+v"(ra), "+v"(rb));                       // (hipcc 7.2 miscompile of bit-cast swap results: fft_wave_half_front)
+        x = __builtin_bit_cast(h2, ra); y = __builtin_bit_cast(h2, rb);
+    };
+    auto swap16 = [](h2& x, h2& y) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+        unsigned ra = r[0], rb = r[1];
+        asm volatile("" : "+v"(ra), "+v"(rb));
+        x = __builtin_bit_cast(h2, ra); y = __builtin_bit_cast(h2, rb);
+    };
+#pragma unroll
+    for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if ((r & 4) == 0) swap16(v[r], v[r + 4]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {                                    // pass 3: twiddle (q3 w64^e2lo)^d3, 4-point DFTs over d3
+        h2 q[4] = {v[e], h_cmul(v[4 + e], tw.z1[e]), h_cmul(v[8 + e], tw.z2[e]), h_cmul(v[12 + e], tw.z3[e])};
+        DftH<4>::run(q);
+        v[e] = q[0]; v[4 + e] = q[1]; v[8 + e] = q[2]; v[12 + e] = q[3];
+    }
+}
+// One group of a low row: yl[g4] = the entry lane (l & 31) loaded for g4 (lanes >= 32 hold a copy of lane l - 32's).
+// v[4 e3 + e2lo] = 2^-10 A_g[k2] in fft_wave_half_front's layout; max_in2 = the largest |pass-1 value|^2 of this lane.
+__device__ __forceinline__ void fft_wave_half_front_low(const uint4v (&yl)[4], h2* v, const HTwiddles& tw, const MfmaBl& b, unsigned& max_in2,
+                                                        h2* pass1_out = nullptr) {
+    unsigned mi = 0u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        unsigned rr01 = __builtin_amdgcn_perm(yl[g][1], yl[g][0], 0x05040100u), rr23 = __builtin_amdgcn_perm(yl[g][3], yl[g][2], 0x05040100u);
+        unsigned ii01 = __builtin_amdgcn_perm(yl[g][1], yl[g][0], 0x07060302u), ii23 = __builtin_amdgcn_perm(yl[g][3], yl[g][2], 0x07060302u);
+        // the upper lanes take the lower lanes' imaginary parts (v_permlane32_swap: upper half of the first <-> lower half of the second)
+        { const auto r = __builtin_amdgcn_permlane32_swap(rr01, ii01, false, false); rr01 = r[0]; ii01 = r[1]; }
+        { const auto r = __builtin_amdgcn_permlane32_swap(rr23, ii23, false, false); rr23 = r[0]; ii23 = r[1]; }
+        const uint2v aw = {rr01, rr23};
+        const half4 a = __builtin_bit_cast(half4, aw);
+        const float4v z = {0.f, 0.f, 0.f, 0.f};
+        const float4v dr = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b.r, z, 0, 0, 0);
+        const float4v di = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b.i, z, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned packed = __builtin_bit_cast(unsigned, h2{(_Float16)dr[i], (_Float16)di[i]});
+            asm volatile("" : "+v"(packed));
+            v[4 * g + i] = __builtin_bit_cast(h2, packed);
+            mi = h_max_bits(mi, h_abs2(v[4 * g + i]));
+        }
+    }
+    max_in2 = mi;
+    if (pass1_out) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) pass1_out[t] = v[t];
+    }
+    fft_wave_half_tail(v, tw);
+}
+#endif  // __HIPCC__
+
 }  // namespace sushi_fft
 #endif

@@ -102,6 +102,10 @@ __device__ __forceinline__ unsigned pack_h2(float re, float im) {
 constexpr int ROW_BYTES = FN * 4;              // a stored spectrum: one 32-bit word per bin
 constexpr int ROWE = FN / sushi_mac::BINS;     // ... as 16-byte entries (four bins: what a lane of mac_kernel owns)
 constexpr float Y_KQ = 8.0f;                  // the quantisation term of a pair's bound, in standard deviations
+// The low band of every spectrum (bins |f| < N/8) is kept a second time, as rows of LROWE entries in the order bound_low_kernel
+// loads them (fft_core.hpp "LOW BAND"): the band-split exclusion multiplies, stores and transforms only these.
+constexpr int LROWE = sushi_fft::LB_ENTRIES;   // 16-byte entries of a low row
+constexpr int LROW_BYTES = LROWE * 16;
 static_assert(FFT_LOGN == 14 && sushi_fft::W_LDS_FLOATS <= LDS_FLOATS && FT == sushi_fft::WNT, "the wave plan is the 16384-point inverse");
 
 // Spectra are STORED in the order the inverse transform loads them (fft_core.hpp "Wave plan": wslot_of_bin): block
@@ -149,15 +153,102 @@ __device__ __attribute__((aligned(16))) const unsigned g_dft16_bh[2 * 64 * 4] = 
 #include "_gen_dft16_f16_bound.inc"
 };
 
+// ... and of bound_low_kernel's (K = 16: the eight d1 a low-band group holds; generated by sushi_amd/build.py)
+__device__ __attribute__((aligned(16))) const unsigned g_dft16_bl[2 * 64 * 2] = {
+#include "_gen_dft16_f16_bound_low.inc"
+};
+
+// What a forward transform leaves for the band-split exclusion.  Thread tid ends with X[tid + 1024 r] in register r: the low band
+// is r = 0, 1, 14, 15 of every thread -- one 16-byte entry of the low row (fft_core.hpp lslot_of_thread) --, and of the other
+// twelve bins the energy of the halves AS STORED is summed: |sum over the bins outside the band of Tt_s(f) Z_j(f)| is at most
+// the product of the two rows' norms outside the band (Cauchy-Schwarz), whatever the phases.
+__device__ __forceinline__ uint4 low_entry_and_rest(const cpx (&v)[sushi_fft::PER], const float sc, float& rest2) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    float e = 0.f;
+#pragma unroll
+    for (int r = 2; r < 14; ++r) {
+        const h2 h = __builtin_bit_cast(h2, pack_h2(v[r].x * sc, v[r].y * sc));
+        e = __builtin_amdgcn_fdot2(h, h, e, false);
+    }
+    rest2 = e;
+    return uint4{pack_h2(v[0].x * sc, v[0].y * sc), pack_h2(v[1].x * sc, v[1].y * sc), pack_h2(v[14].x * sc, v[14].y * sc),
+                 pack_h2(v[15].x * sc, v[15].y * sc)};
+}
+// the low entries of a workgroup into their row (whole KiB per wave through the LDS) and the norm of the rest (red: FT / 64 floats)
+__device__ __forceinline__ float wave_sum_shfl(float w) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) w += __shfl_xor(w, d, 64);
+    return w;
+}
+__device__ __forceinline__ void store_low_row(const uint4 low, const float rest2, const int tid, float* lds, float* red,
+                                              uint4* __restrict__ low_row, float* __restrict__ norm_out) {
+    const float w = wave_sum_shfl(rest2);
+    __syncthreads();                                             // the hand-over's use of the buffer is over
+    uint4* l4 = reinterpret_cast<uint4*>(lds);
+    // (one entry of padding per 128: the eight groups a wave's lanes scatter to are then eight different banks)
+    const int pos = sushi_fft::lslot_of_thread(tid);
+    l4[pos + (pos >> 7)] = low;
+    if ((tid & 63) == 0) red[tid >> 6] = w;
+    __syncthreads();
+    low_row[tid] = l4[tid + (tid >> 7)];
+    if (tid == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < FT / 64; ++i) t += red[i];
+        *norm_out = sqrtf(t) * 1.000002f;
+    }
+}
+// A block spectrum packs TWO real blocks, Z = A + i B (A, B the conjugate-symmetric spectra of the real blocks at j B and
+// j B + H): the real parts of a pair's transform outputs come from A alone, the imaginary parts from B alone, and
+// |A|^2 + |B|^2 = |Z|^2 over a symmetric set of bins -- so bounding the two parts separately, each from its own block's norm,
+// saves the factor sqrt(2) a bound from |Z| pays.  A(f) = (Z(f) + conj Z(N - f)) / 2, B(f) = (Z(f) - conj Z(N - f)) / 2i, of the
+// halves AS STORED; bin N - f of thread tid's register r is register 15 - r of thread FT - tid (tid > 0; tid 0: register
+// (16 - r) % 16 of itself).  out[0 / 1] = the norms of A / B over the bins outside the band.
+__device__ __forceinline__ void real_block_rest_norms(const cpx (&v)[sushi_fft::PER], const float sc, const int tid, float* lds,
+                                                      float* red, float* __restrict__ out_a, float* __restrict__ out_b) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    unsigned* w = reinterpret_cast<unsigned*>(lds);
+    __syncthreads();
+#pragma unroll
+    for (int r = 1; r < 15; ++r) w[(r - 1) * FT + tid] = pack_h2(v[r].x * sc, v[r].y * sc);   // (registers 1 and 14: tid 0's partners of 15 and 2 are not needed; kept simple)
+    __syncthreads();
+    const int pt = tid == 0 ? 0 : FT - tid;
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int r = 2; r < 14; ++r) {
+        const int pr = tid == 0 ? 16 - r : 15 - r;                  // 2 .. 13 -> 13 .. 2 (tid > 0), 14 .. 3 (tid 0)
+        const h2 z = __builtin_bit_cast(h2, pack_h2(v[r].x * sc, v[r].y * sc));
+        const h2 m = __builtin_bit_cast(h2, w[(pr - 1) * FT + pt]);
+        const float ar = (float)z.x + (float)m.x, ai = (float)z.y - (float)m.y;      // Z(f) + conj Z(N - f)
+        const float br = (float)z.x - (float)m.x, bi = (float)z.y + (float)m.y;      // Z(f) - conj Z(N - f)
+        sa += ar * ar + ai * ai;
+        sb += br * br + bi * bi;
+    }
+    sa = wave_sum_shfl(sa); sb = wave_sum_shfl(sb);
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = sa; red[FT / 64 + (tid >> 6)] = sb; }
+    __syncthreads();
+    if (tid == 0) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int i = 0; i < FT / 64; ++i) { ta += red[i]; tb += red[FT / 64 + i]; }
+        *out_a = sqrtf(0.25f * ta) * 1.000004f;
+        *out_b = sqrtf(0.25f * tb) * 1.000004f;
+    }
+}
+static_assert(LROWE == FT && LROW_BYTES + LROWE / 128 * 16 <= LDS_FLOATS * 4 && 14 * FT <= LDS_FLOATS, "one low entry per forward thread");
+
 // ------------------------------------------------------------------------------------------
 // Destination-stream spectra
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(FT)
-void spectra_kernel(const T* __restrict__ raw, int64_t n, uint32_t* __restrict__ spec, const double* __restrict__ stats) {
+void spectra_kernel(const T* __restrict__ raw, int64_t n, uint32_t* __restrict__ spec, const double* __restrict__ stats,
+                    uint4* __restrict__ spec_low, float* __restrict__ znorm_rest, const int64_t norm_stride) {
     const float centre = (float)stats[1];
     const float sz = z_scale_for(stats[0]);
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ float red[2 * (FT / 64)];
     const int tid = threadIdx.x;
     const sushi_fft::Twiddles tw = sushi_fft::load_twiddles<FFT_LOGN, -1>(tid, twiddles());
     const int64_t j = blockIdx.x;
@@ -173,12 +264,16 @@ void spectra_kernel(const T* __restrict__ raw, int64_t n, uint32_t* __restrict__
         v[r].y = (e + FH) < n ? xb : 0.f;
     }
     sushi_fft::fft_split<FFT_LOGN, -1>(v, tid, lds, tw);
+    float rest2;
+    const uint4 low = low_entry_and_rest(v, sz, rest2);
+    real_block_rest_norms(v, sz, tid, lds, red, znorm_rest + norm_stride + j, znorm_rest + 2 * norm_stride + j);
     to_load_order(v, tid, lds);
     uint4* __restrict__ out = reinterpret_cast<uint4*>(spec + (size_t)j * FN);
 #pragma unroll
     for (int u = 0; u < sushi_fft::PER / 4; ++u)
         out[sushi_fft::wslot_uint4(tid, u)] = uint4{pack_h2(v[4 * u].x * sz, v[4 * u].y * sz), pack_h2(v[4 * u + 1].x * sz, v[4 * u + 1].y * sz),
                                                     pack_h2(v[4 * u + 2].x * sz, v[4 * u + 2].y * sz), pack_h2(v[4 * u + 3].x * sz, v[4 * u + 3].y * sz)};
+    store_low_row(low, rest2, tid, lds, red, spec_low + (size_t)j * LROWE, znorm_rest + j);
 }
 
 // last search of [0, n) whose first_seg is <= x
@@ -225,12 +320,15 @@ struct TspecArgs {
     double centre;
     const double* dst_stats;          // the searched stream's stats: [0] largest energy of a pair's span, [1] its centring constant
     int method;                       // SUSHI_HIP_METHOD_CCOEFF_NORMED: spectra of the pattern minus its own mean
+    uint4* tspec_low;                 // [segments of the sub-batch][LROWE] the low band again, in bound_low_kernel's order
+    float* tnorm_rest;                // [segments of the sub-batch] norm of the stored halves outside the band
 };
 
 template <typename T>
 __global__ __launch_bounds__(FT)
 void tspec_kernel(TspecArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ float red[FT / 64];
     const int tid = threadIdx.x;
     const sushi_fft::Twiddles tw = sushi_fft::load_twiddles<FFT_LOGN, -1>(tid, twiddles());
     const int seg = a.sub_first_seg + blockIdx.x;
@@ -274,13 +372,16 @@ void tspec_kernel(TspecArgs a) {
         v[r].y = 0.f;
     }
     sushi_fft::fft_split<FFT_LOGN, -1>(v, tid, lds, tw);
+    const float sc = t_scale / (float)FN;
+    float rest2;
+    const uint4 low = low_entry_and_rest(v, sc, rest2);
     to_load_order(v, tid, lds);
     uint4* __restrict__ out = reinterpret_cast<uint4*>(a.tspec + (size_t)blockIdx.x * FN);
-    const float sc = t_scale / (float)FN;
 #pragma unroll
     for (int u = 0; u < sushi_fft::PER / 4; ++u)
         out[sushi_fft::wslot_uint4(tid, u)] = uint4{pack_h2(v[4 * u].x * sc, v[4 * u].y * sc), pack_h2(v[4 * u + 1].x * sc, v[4 * u + 1].y * sc),
                                                     pack_h2(v[4 * u + 2].x * sc, v[4 * u + 2].y * sc), pack_h2(v[4 * u + 3].x * sc, v[4 * u + 3].y * sc)};
+    store_low_row(low, rest2, tid, lds, red, a.tspec_low + (size_t)blockIdx.x * LROWE, a.tnorm_rest + blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -349,7 +450,7 @@ __device__ __forceinline__ uint4 as_uint4(const sushi_mac::h8 v) { return uint4{
 // Every memory operation of the loop body is unconditional -- lanes without a row to fetch re-fetch a neighbour's,
 // lanes without a valid output store to a dummy line: the compiler then knows how many operations are in flight at every
 // point and waits for exactly the load it needs (a conditional one makes it drain everything, every group).
-template <int SMAX, bool ACCUM, int ZROWS>
+template <int SMAX, bool ACCUM, int ZROWS, int RE>
 __device__ __forceinline__ void mac_chunk(const MacArgs& a, const int c0, const int wv_first, const int wv_last,
                                           const long long pair_lo, const long long pair_hi, const bool lane_chunk,
                                           const sushi_mac::h8 (&tt)[SMAX], const uint4* __restrict__ zsp, const int z_zero,
@@ -369,7 +470,7 @@ __device__ __forceinline__ void mac_chunk(const MacArgs& a, const int c0, const 
     // rows jrow + lrow of one load; blocks past the stream are the all-zero block
     auto load_rows = [&](const int jrow) {
         const int jj = jrow + lrow;
-        return zsp[(size_t)(jj < z_zero ? jj : z_zero) * ROWE];
+        return zsp[(size_t)(jj < z_zero ? jj : z_zero) * RE];
     };
     // a loaded piece into an LDS buffer: the row as it is and rotated
     auto drop = [&](const int buf, const int c, const uint4 piece) {
@@ -412,7 +513,7 @@ __device__ __forceinline__ void mac_chunk(const MacArgs& a, const int c0, const 
                 // (a lane-predicated store instead of the dummy line was tried: the compiler branches around it and
                 // falls back to draining the load queue, tools/experiments/README.md)
                 const bool ok = valid && lane_chunk && jg <= wv_last;
-                u4* __restrict__ dst = reinterpret_cast<u4*>(ok ? yout + (size_t)i * ROWE : dummy);
+                u4* __restrict__ dst = reinterpret_cast<u4*>(ok ? yout + (size_t)i * RE : dummy);
                 float re[sushi_mac::BINS], im[sushi_mac::BINS];
 #pragma unroll
                 for (int k = 0; k < sushi_mac::BINS; ++k) { re[k] = v.re[k] * sy; im[k] = v.im[k] * sy; }   // to the scale of Y
@@ -444,7 +545,7 @@ __device__ __forceinline__ void mac_chunk(const MacArgs& a, const int c0, const 
     }
 }
 
-template <int SMAX, int ZROWS>
+template <int SMAX, int ZROWS, int RE>
 __device__ __forceinline__ void mac_item(const MacArgs& a, const int* __restrict__ item, const int e0, const int slot,
                                          uint4 (*zw)[ZROWS + 1][2][MAC_BPW]) {
     using sushi_mac::h8;
@@ -468,8 +569,8 @@ __device__ __forceinline__ void mac_item(const MacArgs& a, const int* __restrict
     const int wv_first = __builtin_amdgcn_readfirstlane(wave_min_i32(jb0));
     const int wv_last = __builtin_amdgcn_readfirstlane(wave_max_i32(jb1));
     const int wv_seg = __builtin_amdgcn_readfirstlane(wave_max_i32(n_seg));
-    const uint4* __restrict__ tsp = a.tspec + (size_t)first_seg * ROWE + e0;
-    uint4* __restrict__ yout = a.y + (size_t)first_pair * ROWE + e0;
+    const uint4* __restrict__ tsp = a.tspec + (size_t)first_seg * RE + e0;
+    uint4* __restrict__ yout = a.y + (size_t)first_pair * RE + e0;
     const uint4* __restrict__ zsp = a.spec + e0;
     // one 16-byte slot per wave: the invalid lanes of a store instruction then add one request to it instead of a line per
     // search slot (a fifth of mac_kernel's write requests were dummy lines, and the CU's L1 write path is what it waits for)
@@ -478,10 +579,10 @@ __device__ __forceinline__ void mac_item(const MacArgs& a, const int* __restrict
     for (int c0 = 0; c0 < wv_seg; c0 += SMAX) {                 // patterns longer than SMAX segments: SMAX at a time
         h8 tt[SMAX];
 #pragma unroll
-        for (int s = 0; s < SMAX; ++s) tt[s] = (c0 + s) < n_seg ? as_h8(tsp[(size_t)(c0 + s) * ROWE]) : sushi_mac::zero_h8();
+        for (int s = 0; s < SMAX; ++s) tt[s] = (c0 + s) < n_seg ? as_h8(tsp[(size_t)(c0 + s) * RE]) : sushi_mac::zero_h8();
         const bool lane_chunk = c0 < n_seg;
-        if (c0 == 0) mac_chunk<SMAX, false, ZROWS>(a, c0, wv_first, wv_last, pair_lo, pair_hi, lane_chunk, tt, zsp, z_zero, yout, dummy, sy, slot, fb, zw);
-        else if (SMAX == MAC_SMAX_LONG) mac_chunk<SMAX, true, ZROWS>(a, c0, wv_first, wv_last, pair_lo, pair_hi, lane_chunk, tt, zsp, z_zero, yout, dummy, sy, slot, fb, zw);
+        if (c0 == 0) mac_chunk<SMAX, false, ZROWS, RE>(a, c0, wv_first, wv_last, pair_lo, pair_hi, lane_chunk, tt, zsp, z_zero, yout, dummy, sy, slot, fb, zw);
+        else if (SMAX == MAC_SMAX_LONG) mac_chunk<SMAX, true, ZROWS, RE>(a, c0, wv_first, wv_last, pair_lo, pair_hi, lane_chunk, tt, zsp, z_zero, yout, dummy, sy, slot, fb, zw);
     }
 }
 
@@ -489,8 +590,9 @@ __device__ __forceinline__ void mac_item(const MacArgs& a, const int* __restrict
 // owns MAC_CHUNKS / 8 bin chunks, takes them `chunk_group` at a time and walks the items in stream order for each
 // group, so that the workgroups in flight on an XCD are the same few chunks of neighbouring items, whose windows
 // overlap: a row fetched for one is found in that XCD's L2 by the others.
+template <int RE>
 __device__ __forceinline__ void mac_place(const MacArgs& a, int* item_idx, int* e0, int* slot, int* wave) {
-    constexpr int CPX = MAC_CHUNKS / 8;                         // chunks per XCD
+    constexpr int CPX = RE / MAC_BW / 8;                        // chunks per XCD
     const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
     const int cg = a.chunk_group;
     const int per_group = cg * a.n_items;
@@ -504,30 +606,94 @@ __device__ __forceinline__ void mac_place(const MacArgs& a, int* item_idx, int* 
     *slot = lane / MAC_BPW;                                      // which of the item's searches
 }
 
+// RE = entries of a row: ROWE (whole spectra) or LROWE (the low-band rows of the band-split exclusion: the same walk over a
+// quarter of the bins -- rows, pattern spectra and products only have to agree on one order of the entries).
+template <int RE>
 __global__ __launch_bounds__(MAC_THREADS, 3)
 void mac_kernel(MacArgs a) {
     __shared__ uint4 zring[MAC_WAVES][2][MAC_SMAX_SHORT + 1][2][MAC_BPW];   // per wave: two groups of rows, each with its rotation (+ a row nobody reads)
     int item_idx, e0, slot, wave;
-    mac_place(a, &item_idx, &e0, &slot, &wave);
+    mac_place<RE>(a, &item_idx, &e0, &slot, &wave);
     const int* __restrict__ item = a.items + (size_t)item_idx * (1 + MAC_SPW);
     switch (item[0]) {                                          // class c holds patterns of up to 6 (c + 1) segments
-        case 0: mac_item<6, MAC_SMAX_SHORT>(a, item, e0, slot, zring[wave]); break;
-        case 1: mac_item<12, MAC_SMAX_SHORT>(a, item, e0, slot, zring[wave]); break;
-        default: mac_item<18, MAC_SMAX_SHORT>(a, item, e0, slot, zring[wave]); break;
+        case 0: mac_item<6, MAC_SMAX_SHORT, RE>(a, item, e0, slot, zring[wave]); break;
+        case 1: mac_item<12, MAC_SMAX_SHORT, RE>(a, item, e0, slot, zring[wave]); break;
+        default: mac_item<18, MAC_SMAX_SHORT, RE>(a, item, e0, slot, zring[wave]); break;
     }
 }
 
 // Patterns of 19 .. 30 segments (and, 30 at a time, longer ones): up to 30 pattern spectra per lane, two waves per SIMD.
 // One pass instead of mac_kernel's two with Y read back in between (BASELINE configs[4]: half of the events).
+template <int RE>
 __global__ __launch_bounds__(MAC_THREADS, 2)
 void mac_long_kernel(MacArgs a) {
     __shared__ uint4 zring[MAC_WAVES][2][MAC_SMAX_LONG + 1][2][MAC_BPW];
     int item_idx, e0, slot, wave;
-    mac_place(a, &item_idx, &e0, &slot, &wave);
+    mac_place<RE>(a, &item_idx, &e0, &slot, &wave);
     const int* __restrict__ item = a.items + (size_t)item_idx * (1 + MAC_SPW);
     switch (item[0]) {
-        case 3: mac_item<24, MAC_SMAX_LONG>(a, item, e0, slot, zring[wave]); break;
-        default: mac_item<30, MAC_SMAX_LONG>(a, item, e0, slot, zring[wave]); break;
+        case 3: mac_item<24, MAC_SMAX_LONG, RE>(a, item, e0, slot, zring[wave]); break;
+        default: mac_item<30, MAC_SMAX_LONG, RE>(a, item, e0, slot, zring[wave]); break;
+    }
+}
+
+// The multiply-accumulate of LISTED pairs (the band-split exclusion: the pairs transformed first and the pairs the bound
+// could not exclude -- a few per cent of all), over whole rows.  A workgroup = 256 consecutive entries of one listed pair,
+// a lane one entry: its sum over the pattern's segments in mac_kernel's own order and arithmetic (patterns beyond
+// MAC_SMAX_LONG segments: that many per pass, the row re-rounded to halves in between, as mac_long_kernel leaves it).
+struct MacListArgs {
+    const uint4* spec;
+    int64_t spec_blocks;
+    const uint4* tspec;
+    uint4* y;                         // [pairs of the sub-batch][ROWE]
+    const SearchDesc* searches;
+    const TemplConsts* tconst;
+    const int* pairmap;
+    const int* list;                  // pairs to compute (indices inside the sub-batch)
+    const int* count;                 // NULL, or how many entries of `list` exist
+    int n_list;                       // entries of `list` when count is NULL
+    int sub_first_seg;
+    int sub_first_pair;
+};
+constexpr int MACL_THREADS = 256;
+constexpr int MACL_PARTS = ROWE / MACL_THREADS;
+__global__ __launch_bounds__(MACL_THREADS)
+void mac_list_kernel(MacListArgs a) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const int n = a.count ? *a.count : a.n_list;
+    const int z_zero = (int)(a.spec_blocks < 0x7fffffff ? a.spec_blocks : 0x7fffffff);
+    for (long long it = blockIdx.x; it < (long long)n * MACL_PARTS; it += gridDim.x) {
+        const int pr = a.list[it / MACL_PARTS];
+        const int e = (int)(it % MACL_PARTS) * MACL_THREADS + threadIdx.x;
+        const int k = a.pairmap[pr];
+        const SearchDesc sd = a.searches[k];
+        const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
+        const long long I = lay.pair0 + (a.sub_first_pair + pr - sd.first_pair);
+        const float sy = a.tconst[k].mac_scale;
+        const uint4* __restrict__ tsp = a.tspec + (size_t)(sd.first_seg - a.sub_first_seg) * ROWE + e;
+        const uint4* __restrict__ zsp = a.spec + e;
+        float re[sushi_mac::BINS], im[sushi_mac::BINS];
+        for (int c0 = 0; c0 < lay.n_seg; c0 += MAC_SMAX_LONG) {
+            sushi_mac::acc4 acc = sushi_mac::zero_acc();
+            const int s_end = c0 + MAC_SMAX_LONG < lay.n_seg ? c0 + MAC_SMAX_LONG : lay.n_seg;
+            for (int s = c0; s < s_end; ++s) {
+                const long long jj = FFT_STEP * I + s;
+                const sushi_mac::h8 z = as_h8(zsp[(size_t)(jj < z_zero ? jj : z_zero) * ROWE]);
+                const sushi_mac::h8 u = as_h8(tsp[(size_t)s * ROWE]);
+                const sushi_mac::zrow zr = {z, sushi_mac::rot_mi(z)};
+                if (s == c0) acc = sushi_mac::mul4(u, zr); else sushi_mac::mac4(acc, u, zr);
+            }
+            unsigned o[sushi_mac::BINS];
+#pragma unroll
+            for (int q = 0; q < sushi_mac::BINS; ++q) {
+                float r = acc.re[q] * sy, i = acc.im[q] * sy;
+                if (c0 > 0) { r += re[q]; i += im[q]; }
+                const h2 h = {(_Float16)r, (_Float16)i};
+                o[q] = __builtin_bit_cast(unsigned, h);
+                re[q] = (float)h.x; im[q] = (float)h.y;                      // what a later pass reads back
+            }
+            if (s_end == lay.n_seg) a.y[(size_t)pr * ROWE + e] = uint4{o[0], o[1], o[2], o[3]};
+        }
     }
 }
 
@@ -565,6 +731,10 @@ struct IfftArgs {
     int32_t* candbuf;
     int cand_cap;
     RunCounters* counters;
+    // the audit of the exclusion: every transformed pair's lower bound against what the pair really scores
+    const float* slb;                 // [pairs of the sub-batch] or NULL (no exclusion in this run)
+    const unsigned char* audit_mark;  // [pairs of the sub-batch] 1 = the bound had EXCLUDED this pair (transformed as a check)
+    int* viol;                        // [all searches] set to 1 where a lower bound turns out above a real score
 };
 
 constexpr int GQ = 4;                      // positions per window-energy load group
@@ -1000,6 +1170,23 @@ void ifft_kernel(IfftArgs a) {
         // only of pairs that can hold the search's extremum (it used to read every row of every pair: 10 KB per search)
         const bool unc = METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED && unc_any;
         a.pair_lb[pr] = unc ? 0.f : (have_min ? fmaxf(lmin_s - e_pair, 0.f) : __builtin_inff());
+        if (a.slb && have_min && !unc) {
+            // The pair's lower bound (slb_kernel) must not be above any of its exact scores, and the exact score of its best position
+            // is at most lmin_s + e_pair.  Checked on every pair that IS transformed -- among them, per run, one pair per audited
+            // search that the bound had excluded (survivor_kernel): where it fails the search is evaluated at every position.
+            const float s = a.slb[pr], ub = lmin_s + e_pair;
+            const bool audit = a.audit_mark && a.audit_mark[pr];
+            if (s > ub * 1.00001f + 1e-7f) {
+                a.viol[a.first_search + k] = 1;
+                atomicAdd(&a.counters->slb_violations, 1);
+            }
+            if (audit) {
+                atomicAdd(&a.counters->excluded_audited, 1ull);
+                const float ratio = s > 0.f ? s / fmaxf(ub, 1e-30f) : 0.f;
+                if (__float_as_uint(ratio) > *(volatile uint32_t*)&a.counters->max_slb_ratio_bits)
+                    atomicMax(&a.counters->max_slb_ratio_bits, __float_as_uint(ratio));
+            }
+        }
     }
     // a position can be the search's minimum only if score - e <= (smallest score + e) of the search; inside the
     // pair that is score <= lmin_s + 2 e (refine_kernel applies the search-wide threshold to the stored lower bounds);
@@ -1095,7 +1282,101 @@ struct BoundArgs {
     const unsigned long long* gkeys;  // [all searches]
     float* pair_lb;
     RunCounters* counters;
+    // band-split form (bound_low_kernel: `y` = the low rows; slb_kernel adds the rest of the spectrum from the rows' norms)
+    int band;                         // 0: `acc` is over whole rows (bound_kernel); 1: over low rows + norms; 2: norms only (prediction)
+    int sub_first_seg;
+    const float* tnorm_rest;          // [segments of the sub-batch] pattern spectra: norm outside the band
+    const float* znorm_rest;          // [3][norm_stride] block spectra: norm outside the band of Z, of its real block at j B, of the one H on
+    int64_t norm_stride;
+    int* band_votes;                  // [2] prediction: pairs looked at, pairs whose bound leaves room
+    unsigned char* audit_mark;        // [pairs of the sub-batch] 1 = excluded, transformed all the same (the audit of the exclusion)
+    unsigned audit_seq;               // changes from run to run: which excluded pair of a search is audited
+    int audit_every;                  // one search in this many is audited per run (0: none)
 };
+
+// Stage 1 of the band-split form.  A wave takes a PAIR: the eight groups of its low row one after the other (2 KB each, the next
+// one requested before the current one is transformed), each through the three in-wave passes of its half-empty 1024-point
+// transform in packed halves (fft_core.hpp "LOW BAND").  Every lane register holds the same output index k for every group, so
+// the sum over the groups stays in registers: with y_low[2 r'] = sum_g w^(g r') A_g[r' mod 1024],
+//     |y_low[2 r']| <= sum_g |A_g[k]| <= sqrt(8 sum_g |A_g[k]|^2)             (Cauchy-Schwarz over the eight groups)
+// -- one v_dot2 per value, no square root, no exchange between waves -- and the largest of that over k bounds the low band's
+// transform at its sample points (the sum of the groups' separate maxima is 1.7 x looser).  The halves' rounding (header of the
+// packed-half passes: every |A_g| may be 0.2 % + 0.29 x the largest pass-1 value off) goes on top by Minkowski's inequality.
+// Persistent, free-running waves; acc[2 pr] = the bound, acc[2 pr + 1] = the low row's energy (plain stores: one wave per pair).
+__global__ __launch_bounds__(256, 3)
+void bound_low_kernel(BoundArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int waves = gridDim.x * 4;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_items = (int64_t)a.n_pairs * sushi_fft::LB_GROUPS;
+    const sushi_fft::MfmaBl mb = sushi_fft::load_mfma_bl(lane, reinterpret_cast<const sushi_fft::uint2v*>(g_dft16_bl));
+    const sushi_fft::HTwiddles tw = sushi_fft::load_htwiddles(lane, twiddles());
+    const sushi_fft::uint4v* __restrict__ yh = reinterpret_cast<const sushi_fft::uint4v*>(a.y);
+    auto load_item = [&](const int64_t it, sushi_fft::uint4v (&yl)[4]) {
+        // item = pair * 8 + group: a pair's groups are consecutive 2 KB pieces of its row (the upper lanes re-read the lower lanes' entries)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) yl[u] = yh[(size_t)it * (LROWE / sushi_fft::LB_GROUPS) + u * 32 + (lane & 31)];
+    };
+    if (gw >= a.n_pairs) return;
+    sushi_fft::uint4v yl[4], yn[4];
+    load_item((int64_t)gw * sushi_fft::LB_GROUPS, yl);
+    for (int64_t pr = gw; pr < a.n_pairs; pr += waves) {
+        float msum[sushi_fft::PER];
+#pragma unroll
+        for (int r = 0; r < sushi_fft::PER; ++r) msum[r] = 0.f;
+        float q2 = 0.f, d2 = 0.f, dc_re = 0.f, dc_im = 0.f;
+        for (int g = 0; g < sushi_fft::LB_GROUPS; ++g) {
+            // the next group of this pair, or the first of the wave's next pair (the very last one re-requests itself)
+            int64_t nx = pr * sushi_fft::LB_GROUPS + g + 1;
+            if (g == sushi_fft::LB_GROUPS - 1) nx = pr + waves < a.n_pairs ? (pr + waves) * sushi_fft::LB_GROUPS : nx - 1;
+            nx = nx < n_items ? nx : n_items - 1;
+            load_item(nx, yn);
+            __builtin_amdgcn_sched_barrier(0);
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            float q = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const h2 h = __builtin_bit_cast(h2, yl[u][j]);
+                    q = __builtin_amdgcn_fdot2(h, h, q, false);
+                }
+            q2 += lane < 32 ? q : 0.f;
+            if (g == 0) {
+                // Bin 0 apart: a pattern that is not centred (TM_SQDIFF_NORMED) meets whatever a stretch of the stream sums to
+                // beside the stream's mean -- a constant under every output of the pair, often the largest single bin, and
+                // with it in, one of the eight groups dwarfs the others (the Cauchy-Schwarz step above is then 2.8 x loose).
+                // It is entry 0, sub-position 0 of the row (lb_bin_of); its real / imaginary part is added back SIGNED below.
+                const h2 y0 = __builtin_bit_cast(h2, (unsigned)__builtin_amdgcn_readfirstlane((int)yl[0][0]));
+                dc_re = (float)y0.x; dc_im = (float)y0.y;
+                if ((lane & 31) == 0) yl[0][0] = 0u;
+            }
+            sushi_fft::h2 v[sushi_fft::PER];
+            unsigned in2;
+            sushi_fft::fft_wave_half_front_low(yl, v, tw, mb, in2);
+            d2 += 0.0841f * __uint_as_float(wave_max_u32(in2));        // (0.29 x this group's largest pass-1 value)^2
+#pragma unroll
+            for (int r = 0; r < sushi_fft::PER; ++r) msum[r] = __builtin_amdgcn_fdot2(v[r], v[r], msum[r], false);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) yl[u] = yn[u];
+        }
+        unsigned m2 = 0u;
+#pragma unroll
+        for (int r = 0; r < sushi_fft::PER; ++r) m2 = sushi_fft::h_max_bits(m2, __float_as_uint(msum[r]));   // (sums of squares: >= 0)
+        const unsigned wm = wave_max_u32(m2);
+        const float qw = wave_sum_f32(q2);
+        if (lane == 0) {
+            // sqrt(8) (sqrt(max_k sum_g |A_g[k]|^2) (1 + 0.2 %) + sqrt(sum_g (0.29 max |pass-1 value of g|)^2)), the 2^-10 undone:
+            // the modulus of the band (bin 0 aside) at its sample points; sqrt(2) more everywhere between them (fft_core.hpp
+            // "LOW BAND"); plus bin 0's own part, signed -- the cross term's real parts score the pair's first half, its imaginary
+            // parts the second: an UPPER bound of both is what a lower bound of the scores needs
+            float bw = 1.4142137f * 2.8284272f * (sqrtf(__uint_as_float(wm)) * 1.002f + sqrtf(d2)) * 1024.0f + fmaxf(dc_re, dc_im);
+            if (wm >= 0x7f800000u || !(d2 < __builtin_inff())) bw = __builtin_inff();
+            a.acc[2 * (size_t)pr] = bw;
+            a.acc[2 * (size_t)pr + 1] = qw * 1.000001f;
+        }
+    }
+}
 
 // Stage 1: the transform part.  An item = (pair, n1): one wave's decimated share of one pair's Y (4 KB), three passes, the
 // largest |A_n1[k2]|.  Waves are persistent and free-running -- no workgroup-wide step: every wave walks its own items and
@@ -1221,8 +1502,37 @@ void slb_kernel(BoundArgs a) {
         }
     }
     const float wlb = wave_min_f32(wl);
+    // band-split form: what the bins outside the band can add to any output of the pair's transform, from the norms of the rows
+    // that meet (Cauchy-Schwarz per segment, the triangle inequality over the segments; the stored halves' own rounding and
+    // their subnormal floor on top; a pattern of more than MAC_SMAX_LONG segments re-rounds its partial row once per pass)
+    float b_rest = 0.f;
+    if (a.band) {
+        // The real parts of the pair's outputs meet the real blocks at 6 I + s, the imaginary parts those H samples on: each from
+        // its own block's norm (real_block_rest_norms) -- the larger of the two sums bounds both parts.  That split assumes the
+        // pattern rows conjugate-symmetric (spectra of real segments); what their stored halves lack of it (half an ulp per bin
+        // and the float32 transform's own asymmetry: < 1.5e-3 of a row's norm) meets the whole |Z|.
+        const float* __restrict__ tn = a.tnorm_rest + (sd.first_seg - a.sub_first_seg);
+        const float* __restrict__ zn = a.znorm_rest;
+        const float* __restrict__ an = a.znorm_rest + a.norm_stride;
+        const float* __restrict__ bn = a.znorm_rest + 2 * a.norm_stride;
+        float pz = 0.f, pa = 0.f, pb = 0.f;
+        for (int s = lane; s < n_seg; s += 64) {
+            const int64_t jj = kA + s < a.nb ? kA + s : a.nb;
+            const float t = tn[s];
+            pz += t * zn[jj]; pa += t * an[jj]; pb += t * bn[jj];
+        }
+        pz = wave_sum_f32(pz); pa = wave_sum_f32(pa); pb = wave_sum_f32(pb);
+        const int passes = (n_seg + MAC_SMAX_LONG - 1) / MAC_SMAX_LONG;
+        b_rest = (fmaxf(pa, pb) + 1.5e-3f * pz) * tc.mac_scale * (1.0006f + 0.0005f * (float)passes) + 1e-3f;
+    }
     if (lane == 0) {
-        const float B = a.acc[2 * (size_t)pr], qmax = a.acc[2 * (size_t)pr + 1];
+        float B = a.acc[2 * (size_t)pr], qmax = a.acc[2 * (size_t)pr + 1];
+        if (a.band) {
+            // acc[1] is the low band's energy, and the rest's is at most the square of its sum of moduli -- as one sixteenth of a
+            // row's energy, the unit the model below takes
+            B = (a.band == 2 ? 0.f : B) + b_rest;                 // (bound_low_kernel's value is complete: sqrt(2) and bin 0 are in it)
+            qmax = ((a.band == 2 ? 0.f : qmax) + b_rest * b_rest) * (1.0f / (float)(FT / 64));
+        }
         // energy of the samples that enter this pair's transforms, as they are (zn) and centred (zn_c): score_pair's
         const int64_t iA = kA < a.nb ? kA : a.nb, iB = kA + n_seg + 2 * FFT_VB < a.nb ? kA + n_seg + 2 * FFT_VB : a.nb;
         const double u0 = a.ubase[iA], u1 = a.ubase[iB], s0 = a.sbase[iA], s1 = a.sbase[iB];
@@ -1237,18 +1547,32 @@ void slb_kernel(BoundArgs a) {
         // what the exact cross term of any position of this pair can reach: the bound of the transform's outputs (its own
         // float32 rounding included in the factor), the FFT stage's error, the packed halves' modelled error
         const double tn = CC ? (tc.inv_tnorm_c > 0.f ? 1.0 / (double)tc.inv_tnorm_c : 0.0) : (double)tc.tnorm;
-        const double ymax = (double)B * (double)tc.inv_scale * 1.00002 + 5.9604645e-8 * (double)FFT_KE * (CC ? fmax(zn, zn_c) : zn_c) * tn +
+        // (an UPPER bound of the signed cross term: the band-split form's may be negative)
+        const double ymax = (double)B * (double)tc.inv_scale + fabs((double)B) * (double)tc.inv_scale * 2e-5 + 5.9604645e-8 * (double)FFT_KE * (CC ? fmax(zn, zn_c) : zn_c) * tn +
                             (double)Y_KQ * sigma_y;
         float slb = -__builtin_inff();
+        bool room = false;          // (prediction) the bound, with nothing but the norms outside the band in it, keeps 55 % of what a zero cross term would score
         if (CC) {
-            if (wlb > 0.f && wlb < __builtin_inff() && !tc.flat && tn > 0.0)
+            if (wlb > 0.f && wlb < __builtin_inff() && !tc.flat && tn > 0.0) {
                 slb = (float)(1.0 - ymax / (tn * sqrt((double)wlb)) * 1.000001);
+                room = slb > 0.55f;
+            }
         } else {
-            const double a0 = (tc.tU - 2.0 * (double)tc.c_sum_t) - 2.0 * ymax;
-            if (wlb > 0.f && wlb < __builtin_inff() && a0 < (double)wlb && tc.tU > 0.0)
+            const double t0 = tc.tU - 2.0 * (double)tc.c_sum_t;
+            const double a0 = t0 - 2.0 * ymax;
+            if (wlb > 0.f && wlb < __builtin_inff() && a0 < (double)wlb && tc.tU > 0.0) {
                 slb = (float)((a0 + (double)wlb) / (sqrt((double)wlb) * (double)tc.tnorm) * 0.999999);
+                room = a0 + (double)wlb >= 0.55 * (t0 + (double)wlb);
+            }
         }
         a.slb[pr] = slb;
+        if (a.band == 2) {
+            // prediction: with NOTHING from the low band, does the rest alone leave the bound room to exclude?  (The scores'
+            // scale is what a zero cross term gives -- small for streams that sit on a large mean --: the rest may take 45 % of it,
+            // the low band's sum and the match's own score need the other half.)
+            atomicAdd(a.band_votes, 1);
+            if (room) atomicAdd(a.band_votes + 1, 1);
+        }
     }
 }
 
@@ -1286,14 +1610,24 @@ void survivor_kernel(BoundArgs a) {
     if (b < a.n_pairs) {
         pr = a.order[b];
         const int k = a.pairmap[pr];
+        bool audit = false;
         if (a.plist[k] != pr) {
             const unsigned long long g = a.gkeys[a.first_search + k];
             const float U = g == NO_KEY ? __builtin_inff() : key_score(g);
             // (a search whose best score is 1 -- no match anywhere, every score clamped to 1 -- ties everywhere: nothing is excluded)
             const bool excluded = U < 0.9999f && a.slb[pr] > U * 1.000001f + 1e-7f;
-            if (excluded) a.pair_lb[pr] = __builtin_inff();
-            keep = !excluded;
+            if (excluded && a.audit_every > 0 && ((unsigned)(a.first_search + k) + a.audit_seq) % (unsigned)a.audit_every == 0u) {
+                // the audit of the exclusion: one hashed pair of the search; if the bound excluded it, it is transformed all the
+                // same and ifft_kernel holds its bound to what it really scores
+                const SearchDesc sd = a.searches[k];
+                const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
+                const unsigned h = ((unsigned)(a.first_search + k) * 2654435761u + a.audit_seq * 40503u) >> 9;
+                audit = (int)(h % (unsigned)lay.n_pairs) == a.sub_first_pair + pr - sd.first_pair;
+            }
+            if (excluded && !audit) a.pair_lb[pr] = __builtin_inff();
+            keep = !excluded || audit;
         }
+        if (a.audit_mark) a.audit_mark[pr] = audit ? 1 : 0;
     }
     const unsigned long long m = __ballot(keep);
     const int lane = threadIdx.x & 63;
@@ -1442,7 +1776,8 @@ inline int64_t cand_capacity(int64_t pairs) {
 }
 
 // bytes of workspace for one sub-batch of `pairs` block pairs, `segs` pattern segments and `searches` searches
-struct WsLayout { size_t tspec, y, cand, pair_lb, pairmap, tconst, tiles, candbuf, dummy, slb, acc, plist, slist, scount, citems, total; };
+struct WsLayout { size_t tspec, y, cand, pair_lb, pairmap, tconst, tiles, candbuf, dummy, slb, acc, plist, slist, scount, citems,
+                  tspec_low, ylow, tnorm_rest, audit_mark, total; };
 inline WsLayout ws_layout(int64_t pairs, int64_t segs, int64_t searches) {
     WsLayout w;
     size_t o = 0;
@@ -1459,8 +1794,13 @@ inline WsLayout ws_layout(int64_t pairs, int64_t segs, int64_t searches) {
     w.acc = o; o += align_up((size_t)pairs * 2 * sizeof(float), 256);
     w.plist = o; o += align_up((size_t)searches * sizeof(int), 256);
     w.slist = o; o += align_up((size_t)pairs * sizeof(int), 256);
-    w.scount = o; o += 256;                                                      // [0] survivors, [1] collect items
+    w.scount = o; o += 256;                                                      // [0] survivors, [1] collect items, [2..3] band prediction votes
     w.citems = o; o += align_up((size_t)pairs * sizeof(int), 256);
+    // band-split exclusion: low-band rows of the pattern spectra and of the products, the pattern rows' norms outside the band
+    w.tspec_low = o; o += align_up((size_t)segs * LROW_BYTES, 256);
+    w.ylow = o; o += align_up((size_t)pairs * LROW_BYTES, 256);
+    w.tnorm_rest = o; o += align_up((size_t)segs * sizeof(float), 256);
+    w.audit_mark = o; o += align_up((size_t)pairs, 256);
     w.total = o;
     return w;
 }
@@ -1632,7 +1972,7 @@ int choose_direct_variant(const SushiHipRequest* req, int n) {
 }
 
 // device-memory layout of a batch
-struct BatchLayout { size_t desc, keys, flags, flag_list, sub_flagged, counters, order, items, ws, total; };
+struct BatchLayout { size_t desc, keys, flags, viol, flag_list, sub_flagged, counters, order, items, ws, total; };
 
 BatchLayout batch_layout(int n, int path, int64_t total_pairs, size_t n_item_ints, size_t ws_bytes) {
     BatchLayout b;
@@ -1640,6 +1980,7 @@ BatchLayout batch_layout(int n, int path, int64_t total_pairs, size_t n_item_int
     b.desc = o; o += align_up((size_t)n * sizeof(SearchDesc), 256);
     b.keys = o; o += align_up((size_t)2 * n * sizeof(unsigned long long), 256);
     b.flags = o; o += align_up((size_t)n * sizeof(int), 256);
+    b.viol = o; o += align_up((size_t)n * sizeof(int), 256);
     b.flag_list = o; o += align_up((size_t)n * sizeof(int), 256);
     b.sub_flagged = o; o += 256;
     b.counters = o; o += align_up(sizeof(RunCounters), 256);
@@ -1688,6 +2029,12 @@ struct SushiHipBatch {
     const SushiHipStream* dst;
     const SushiHipStream* src;
     int n, path, variant, method, exclusion;
+    int band;                           // the exclusion's form in AUTO / ALWAYS: -1 not decided yet, 0 whole rows (bound_kernel), 1 band-split
+    int band_decided_method;            // ... which was decided for this method (the pattern spectra differ)
+    int band_votes[2];                  // what the decision was taken from: pairs looked at, pairs whose bound leaves room
+    unsigned run_seq;                   // runs so far: rotates which excluded pairs are audited
+    int audit_every;                    // one search in this many has one excluded pair transformed as a check, per run
+    int last_band;                      // form of the exclusion the last run's last sub-batch used (-1: none)
     int64_t n_tiles;
     int64_t direct_pairs;               // pairs of the last run's sub-batches that were transformed without the exclusion
     std::vector<SearchDesc> descs;
@@ -1710,7 +2057,9 @@ int sushi_hip_fft_block(void) { return FFT_SEG; }
 int sushi_hip_fft_slot_of_bin(int bin) { return (bin < 0 || bin >= FN) ? -1 : sushi_fft::mslot_of_bin(bin); }
 
 size_t sushi_hip_stream_spectra_bytes(int64_t n) {
-    return n <= 0 ? 0 : (size_t)((n + FFT_SEG - 1) / FFT_SEG + 1) * ROW_BYTES;
+    if (n <= 0) return 0;
+    const size_t rows = (size_t)((n + FFT_SEG - 1) / FFT_SEG + 1);
+    return rows * ROW_BYTES + rows * LROW_BYTES + 3 * align_up(rows * sizeof(float), 256);   // norms outside the band: of Z, of its two real blocks
 }
 
 int sushi_hip_fft_layout(int64_t win_start, int32_t n_pos, int32_t tmpl_len, int32_t* n_pairs, int32_t* n_seg) {
@@ -1728,15 +2077,23 @@ int sushi_hip_stream_add_spectra(SushiHipStream* s, void* mem_dev, size_t mem_by
     if (mem_bytes < need) return SUSHI_HIP_ENOSPACE;
     if (s->blocks >= 0x7fffffff) return SUSHI_HIP_EINVAL;
     // one block more than the stream has: its samples are all past the end, so its spectrum is zero
+    const size_t rows = (size_t)s->blocks + 1;
+    uint4* low = (uint4*)((char*)mem_dev + rows * ROW_BYTES);
+    float* zn = (float*)((char*)mem_dev + rows * ROW_BYTES + rows * LROW_BYTES);
     if (s->dtype == SUSHI_HIP_F32)
         hipLaunchKernelGGL(spectra_kernel<float>, dim3((unsigned)s->blocks + 1), dim3(FT), 0, (hipStream_t)hip_stream,
-                           (const float*)s->raw, s->n, (uint32_t*)mem_dev, (const double*)s->stats);
+                           (const float*)s->raw, s->n, (uint32_t*)mem_dev, (const double*)s->stats, low, zn,
+                           (int64_t)(align_up(rows * sizeof(float), 256) / sizeof(float)));
     else
         hipLaunchKernelGGL(spectra_kernel<uint8_t>, dim3((unsigned)s->blocks + 1), dim3(FT), 0, (hipStream_t)hip_stream,
-                           (const uint8_t*)s->raw, s->n, (uint32_t*)mem_dev, (const double*)s->stats);
+                           (const uint8_t*)s->raw, s->n, (uint32_t*)mem_dev, (const double*)s->stats, low, zn,
+                           (int64_t)(align_up(rows * sizeof(float), 256) / sizeof(float)));
     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
     s->spec = mem_dev;
-    s->spec_bytes = need;
+    s->spec_low = low;
+    s->znorm_rest = zn;
+    s->norm_stride = (int64_t)(align_up(rows * sizeof(float), 256) / sizeof(float));
+    s->spec_bytes = rows * ROW_BYTES;
     return SUSHI_HIP_OK;
 }
 
@@ -1774,6 +2131,11 @@ int sushi_hip_batch_create(const SushiHipStream* dst, const SushiHipStream* src,
     std::unique_ptr<SushiHipBatch> guard(b);                     // freed on every early return and on an exception
     b->dst = dst; b->src = src; b->n = n; b->path = path; b->variant = variant; b->method = SUSHI_HIP_METHOD_SQDIFF_NORMED;
     b->exclusion = SUSHI_HIP_EXCLUDE_AUTO;
+    b->band = -1; b->last_band = -1; b->band_decided_method = -1; b->band_votes[0] = b->band_votes[1] = 0; b->run_seq = 0; b->audit_every = 1;
+    {
+        const char* e = getenv("SUSHI_HIP_AUDIT_EVERY");      // (measurements: 0 = no excluded pair is audited)
+        if (e && *e) { const int v = atoi(e); b->audit_every = v < 0 ? 0 : v; }
+    }
     b->mem = (char*)mem_dev; b->last_stream = nullptr; b->ran = false; b->uploaded = nullptr;
     int rc = make_descs(req_host, n, variant, b->descs, &b->n_tiles);
     double flops = 0.0, abytes = 0.0;
@@ -1837,7 +2199,7 @@ int sushi_hip_batch_set_method(SushiHipBatch* b, int method) {
 }
 
 int sushi_hip_batch_set_exclusion(SushiHipBatch* b, int mode) {
-    if (!b || mode < SUSHI_HIP_EXCLUDE_AUTO || mode > SUSHI_HIP_EXCLUDE_NEVER) return SUSHI_HIP_EINVAL;
+    if (!b || mode < SUSHI_HIP_EXCLUDE_AUTO || mode > SUSHI_HIP_EXCLUDE_WHOLE) return SUSHI_HIP_EINVAL;
     b->exclusion = mode;
     return SUSHI_HIP_OK;
 }
@@ -1875,6 +2237,11 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
     ProfCall* pc = nullptr;
     if (g_prof_on) { g_prof.emplace_back(); pc = &g_prof.back(); }
 
+    int* viol = (int*)(b->mem + b->lay.viol);
+    if (hipMemsetAsync(viol, 0, (size_t)n_search * sizeof(int32_t), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+    const unsigned run_seq = b->run_seq++;
+    const bool ccm = b->method == SUSHI_HIP_METHOD_CCOEFF_NORMED;
+
     // (A two-stream variant that overlapped the multiply-accumulate of sub-batch n+1 with the inverse
     // transforms of sub-batch n was measured 5 % slower: both kernels only contend.)
     for (const SubBatch& sbt : b->plan.subs) {
@@ -1889,32 +2256,94 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         TemplConsts* tconst = (TemplConsts*)(wsp + wl.tconst);
         TileDesc* tiles = (TileDesc*)(wsp + wl.tiles);
         int32_t* candbuf = (int32_t*)(wsp + wl.candbuf);
+        uint4* tspec_low = (uint4*)(wsp + wl.tspec_low);
+        uint4* ylow = (uint4*)(wsp + wl.ylow);
+        float* tnorm_rest = (float*)(wsp + wl.tnorm_rest);
+        int* scount = (int*)(wsp + wl.scount);
 
         hipEvent_t t0 = prof_begin(pc, st);
         TspecArgs ta;
         ta.src_raw = src->raw; ta.searches = searches_dev + sbt.a0; ta.n_sub = n_sub; ta.sub_first_seg = sbt.first_seg;
         ta.tspec = tspec; ta.sub_first_pair = sbt.first_pair; ta.pairmap = pairmap; ta.tconst = tconst;
         ta.src_s1 = src->s1; ta.src_s2 = src->s2; ta.centre = r.centre; ta.dst_stats = dst->stats; ta.method = b->method;
+        ta.tspec_low = tspec_low; ta.tnorm_rest = tnorm_rest;
         if (src->dtype == SUSHI_HIP_F32) hipLaunchKernelGGL(tspec_kernel<float>, dim3((unsigned)sbt.segs), dim3(FT), 0, st, ta);
         else hipLaunchKernelGGL(tspec_kernel<uint8_t>, dim3((unsigned)sbt.segs), dim3(FT), 0, st, ta);
         if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
         prof_end(pc, t0, SUSHI_HIP_STAGE_TSPEC, st);
 
+        // The exclusion costs a pass over Y (~16 ns per pair) and half a dozen launches (~60 us); transforming a pair ~37 ns:
+        // it pays from ~3000 pairs on, plus two per search (the pairs transformed first are transformed either way).
+        const bool exclude = b->exclusion == SUSHI_HIP_EXCLUDE_ALWAYS || b->exclusion == SUSHI_HIP_EXCLUDE_BAND ||
+                             b->exclusion == SUSHI_HIP_EXCLUDE_WHOLE ||
+                             (b->exclusion == SUSHI_HIP_EXCLUDE_AUTO && sbt.pairs > 3000 + 2 * (int64_t)n_sub);
+        BoundArgs ba;
+        memset(&ba, 0, sizeof(ba));
+        ba.dst_stats = dst->stats; ba.searches = searches_dev + sbt.a0; ba.sub_first_pair = sbt.first_pair;
+        ba.first_search = sbt.a0; ba.dst_len = dst->n; ba.pairmap = pairmap; ba.tconst = tconst; ba.ubase = dst->base;
+        ba.sbase = dst->base + (dst->blocks + 1); ba.nb = dst->blocks; ba.coarse = dst->coarse; ba.nc = dst->nc;
+        ba.slb = (float*)(wsp + wl.slb); ba.n_sub = n_sub; ba.n_pairs = (int)sbt.pairs; ba.plist = (int*)(wsp + wl.plist);
+        ba.slist = (int*)(wsp + wl.slist); ba.scount = scount; ba.order = order + sbt.first_pair;
+        ba.gkeys = gkeys; ba.pair_lb = pair_lb; ba.counters = counters;
+        ba.acc = (float*)(wsp + wl.acc);
+        ba.sub_first_seg = sbt.first_seg; ba.tnorm_rest = tnorm_rest; ba.znorm_rest = dst->znorm_rest; ba.norm_stride = dst->norm_stride; ba.band_votes = scount + 2;
+        ba.audit_mark = (unsigned char*)(wsp + wl.audit_mark); ba.audit_seq = run_seq; ba.audit_every = b->audit_every;
+        auto launch_slb = [&](const BoundArgs& x) {
+            if (ccm) hipLaunchKernelGGL(slb_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3((unsigned)((sbt.pairs + 3) / 4)), dim3(256), 0, st, x);
+            else hipLaunchKernelGGL(slb_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3((unsigned)((sbt.pairs + 3) / 4)), dim3(256), 0, st, x);
+            return launch_ok();
+        };
+
+        // Which form of the exclusion: the band-split form multiplies, stores and transforms only the low band of
+        // every spectrum and bounds the rest by the rows' norms -- a quarter of the bytes and a third of the instructions, IF the
+        // streams keep most of their energy in the band (audio does; white noise does not).  Decided once per batch and method, on
+        // the device's own numbers: with nothing at all from the low band, does the rest alone leave the bound room to exclude?
+        // (One small kernel over the first sub-batch's pairs and one 8-byte read-back, in the first run only.)
+        int band = 0;
+        b->last_band = -1;
+        if (exclude) {
+            if (b->exclusion == SUSHI_HIP_EXCLUDE_BAND) band = 1;
+            else if (b->exclusion == SUSHI_HIP_EXCLUDE_WHOLE) band = 0;
+            else {
+                if (b->band < 0 || b->band_decided_method != b->method) {
+                    if (hipMemsetAsync(scount + 2, 0, 2 * sizeof(int), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+                    BoundArgs bp = ba;
+                    bp.band = 2;
+                    if (launch_slb(bp) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+                    if (hipMemcpyAsync(b->band_votes, scount + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                        hipStreamSynchronize(st) != hipSuccess)
+                        return SUSHI_HIP_ELAUNCH;
+                    b->band = b->band_votes[0] > 0 && (double)b->band_votes[1] >= 0.9 * (double)b->band_votes[0] ? 1 : 0;
+                    b->band_decided_method = b->method;
+                }
+                band = b->band;
+            }
+            b->last_band = band;
+        }
+
         t0 = prof_begin(pc, st);
         {
             MacArgs ma;
-            ma.spec = (const uint4*)dst->spec; ma.spec_blocks = dst->blocks; ma.tspec = (const uint4*)tspec;
-            ma.y = y; ma.searches = searches_dev + sbt.a0; ma.tconst = tconst; ma.sub_first_seg = sbt.first_seg;
+            ma.spec_blocks = dst->blocks;
+            ma.searches = searches_dev + sbt.a0; ma.tconst = tconst; ma.sub_first_seg = sbt.first_seg;
             ma.sub_first_pair = sbt.first_pair;
             ma.dummy = (uint4*)(wsp + wl.dummy);
+            if (band) { ma.spec = (const uint4*)dst->spec_low; ma.tspec = tspec_low; ma.y = ylow; }
+            else { ma.spec = (const uint4*)dst->spec; ma.tspec = (const uint4*)tspec; ma.y = y; }
             for (int kern = 0; kern < 2; ++kern) {
                 if (sbt.item_count[kern] == 0) continue;
                 ma.items = items + (size_t)sbt.item_first[kern] * (1 + MAC_SPW);
                 ma.n_items = sbt.item_count[kern];
-                ma.chunk_group = sbt.chunk_group[kern];
-                const dim3 grid((unsigned)MAC_CHUNKS * (unsigned)ma.n_items);
-                if (kern == 0) hipLaunchKernelGGL(mac_kernel, grid, dim3(MAC_THREADS), 0, st, ma);
-                else hipLaunchKernelGGL(mac_long_kernel, grid, dim3(MAC_THREADS), 0, st, ma);
+                const int chunks = (band ? LROWE : ROWE) / MAC_BW;
+                ma.chunk_group = std::min(sbt.chunk_group[kern], chunks / 8);
+                const dim3 grid((unsigned)chunks * (unsigned)ma.n_items);
+                if (band) {
+                    if (kern == 0) hipLaunchKernelGGL(mac_kernel<LROWE>, grid, dim3(MAC_THREADS), 0, st, ma);
+                    else hipLaunchKernelGGL(mac_long_kernel<LROWE>, grid, dim3(MAC_THREADS), 0, st, ma);
+                } else {
+                    if (kern == 0) hipLaunchKernelGGL(mac_kernel<ROWE>, grid, dim3(MAC_THREADS), 0, st, ma);
+                    else hipLaunchKernelGGL(mac_long_kernel<ROWE>, grid, dim3(MAC_THREADS), 0, st, ma);
+                }
                 if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             }
         }
@@ -1933,16 +2362,22 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         ia.usrel = dst->usrel; ia.sbase = dst->base + (dst->blocks + 1);
         ia.flags = flags; ia.flag_list = flag_list; ia.sub_flagged = sub_flagged; ia.tiles = tiles; ia.candbuf = candbuf;
         ia.cand_cap = (int)cand_capacity(sbt.pairs); ia.counters = counters;
-        const bool ccm = b->method == SUSHI_HIP_METHOD_CCOEFF_NORMED;
+        ia.viol = viol;
         auto launch_ifft = [&](const IfftArgs& x, unsigned grid) {
             if (ccm) hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3(grid), dim3(FT), 0, st, x);
             else hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3(grid), dim3(FT), 0, st, x);
             return launch_ok();
         };
-        // The exclusion costs a pass over Y (~16 ns per pair) and half a dozen launches (~60 us); transforming a pair ~37 ns:
-        // it pays from ~3000 pairs on, plus two per search (the pairs transformed first are transformed either way).
-        const bool exclude = b->exclusion == SUSHI_HIP_EXCLUDE_ALWAYS ||
-                             (b->exclusion == SUSHI_HIP_EXCLUDE_AUTO && sbt.pairs > 3000 + 2 * (int64_t)n_sub);
+        // the whole rows of LISTED pairs (band-split form: nothing but the low band exists until a pair is to be transformed)
+        auto launch_mac_list = [&](const int* list, const int* count, int n_list) {
+            MacListArgs la;
+            la.spec = (const uint4*)dst->spec; la.spec_blocks = dst->blocks; la.tspec = (const uint4*)tspec; la.y = y;
+            la.searches = searches_dev + sbt.a0; la.tconst = tconst; la.pairmap = pairmap; la.list = list; la.count = count;
+            la.n_list = n_list; la.sub_first_seg = sbt.first_seg; la.sub_first_pair = sbt.first_pair;
+            const int64_t want = (int64_t)n_list * MACL_PARTS;
+            hipLaunchKernelGGL(mac_list_kernel, dim3((unsigned)std::min<int64_t>(want, 256 * 32)), dim3(MACL_THREADS), 0, st, la);
+            return launch_ok();
+        };
         if (!exclude) {
             // every pair, in the L2-friendly schedule (what round 3 did for every batch)
             if (launch_ifft(ia, (unsigned)sbt.pairs) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
@@ -1951,36 +2386,32 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             // A lower bound of every pair's scores first (three of the transform's four passes, no scoring); then the most
             // promising pair of every search, which leaves the search's threshold; then whatever the bound could not exclude
             // (header of bound_kernel)
-            BoundArgs ba;
-            memset(&ba, 0, sizeof(ba));
-            ba.y = (const uint2*)y; ba.dst_stats = dst->stats; ba.searches = searches_dev + sbt.a0; ba.sub_first_pair = sbt.first_pair;
-            ba.first_search = sbt.a0; ba.dst_len = dst->n; ba.pairmap = pairmap; ba.tconst = tconst; ba.ubase = dst->base;
-            ba.sbase = dst->base + (dst->blocks + 1); ba.nb = dst->blocks; ba.coarse = dst->coarse; ba.nc = dst->nc;
-            ba.slb = (float*)(wsp + wl.slb); ba.n_sub = n_sub; ba.n_pairs = (int)sbt.pairs; ba.plist = (int*)(wsp + wl.plist);
-            ba.slist = (int*)(wsp + wl.slist); ba.scount = (int*)(wsp + wl.scount); ba.order = order + sbt.first_pair;
-            ba.gkeys = gkeys; ba.pair_lb = pair_lb; ba.counters = counters;
-            ba.acc = (float*)(wsp + wl.acc);
+            ba.band = band;
+            ba.y = band ? (const uint2*)ylow : (const uint2*)y;
             if (hipMemsetAsync(ba.acc, 0, (size_t)sbt.pairs * 2 * sizeof(float), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
             {
                 // persistent waves: four workgroups of four per CU (the kernel's register budget), fewer for a small batch
-                const int64_t want = (sbt.pairs * 16 + BOUND_THREADS / 64 - 1) / (BOUND_THREADS / 64);
-                const unsigned grid = (unsigned)std::min<int64_t>(want, 256 * 4);
-                hipLaunchKernelGGL(bound_kernel, dim3(grid), dim3(BOUND_THREADS), 0, st, ba);
+                const int per_pair = band ? 1 : 16;                  // bound_low_kernel: a wave per pair
+                const int64_t want = (sbt.pairs * per_pair + BOUND_THREADS / 64 - 1) / (BOUND_THREADS / 64);
+                const unsigned grid = (unsigned)std::min<int64_t>(want, 256 * (band ? 3 : 4));   // (what is resident at each kernel's registers)
+                if (band) hipLaunchKernelGGL(bound_low_kernel, dim3(grid), dim3(BOUND_THREADS), 0, st, ba);
+                else hipLaunchKernelGGL(bound_kernel, dim3(grid), dim3(BOUND_THREADS), 0, st, ba);
                 if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-                if (ccm) hipLaunchKernelGGL(slb_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3((unsigned)((sbt.pairs + 3) / 4)), dim3(256), 0, st, ba);
-                else hipLaunchKernelGGL(slb_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3((unsigned)((sbt.pairs + 3) / 4)), dim3(256), 0, st, ba);
-                if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+                if (launch_slb(ba) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             }
             prof_end(pc, t0, SUSHI_HIP_STAGE_BOUND, st);
             t0 = prof_begin(pc, st);
             hipLaunchKernelGGL(pilot_kernel, dim3((unsigned)n_sub), dim3(64), 0, st, ba);
             if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             IfftArgs ip = ia;
+            ip.slb = ba.slb; ip.audit_mark = nullptr;              // (the pairs transformed first are nobody's excluded pairs)
             ip.order = ba.plist; ip.count = nullptr;
+            if (band && launch_mac_list(ba.plist, nullptr, n_sub) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             if (launch_ifft(ip, (unsigned)n_sub) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             hipLaunchKernelGGL(survivor_kernel, dim3((unsigned)((sbt.pairs + 255) / 256)), dim3(256), 0, st, ba);
             if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-            ip.order = ba.slist; ip.count = ba.scount;
+            ip.order = ba.slist; ip.count = ba.scount; ip.audit_mark = ba.audit_mark;
+            if (band && launch_mac_list(ba.slist, ba.scount, (int)sbt.pairs) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             if (launch_ifft(ip, (unsigned)sbt.pairs) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
         }
         prof_end(pc, t0, SUSHI_HIP_STAGE_IFFT, st);
@@ -1991,6 +2422,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         rp.cand = cand; rp.pair_lb = pair_lb; rp.gkeys = gkeys; rp.keys = keys; rp.flags = flags; rp.flag_list = flag_list;
         rp.sub_flagged = sub_flagged; rp.counters = counters; rp.delta = (float)delta; rp.method = b->method;
         rp.citems = (int*)(wsp + wl.citems); rp.n_citems = (int*)(wsp + wl.scount) + 1;
+        rp.viol = viol;
         ia.citems = rp.citems; ia.n_citems = rp.n_citems;
         int rc = launch_refine(rp, st);
         if (rc != SUSHI_HIP_OK) return rc;
@@ -2035,6 +2467,11 @@ int sushi_hip_batch_diagnostics(SushiHipBatch* b, SushiHipBatchDiag* diag, float
     memcpy(&diag->max_bound_ratio_noncandidate, &c.max_ratio_audit_bits, sizeof(float));
     diag->audited = (int64_t)c.audited;
     diag->pairs_transformed = (int64_t)c.pairs_transformed + b->direct_pairs;
+    diag->excluded_audited = (int64_t)c.excluded_audited;
+    memcpy(&diag->max_slb_ratio_excluded, &c.max_slb_ratio_bits, sizeof(float));
+    diag->slb_violations = c.slb_violations;
+    diag->band = b->last_band;
+    diag->band_votes[0] = b->band_votes[0]; diag->band_votes[1] = b->band_votes[1];
     std::vector<int32_t> fl((size_t)b->n);
     if (hipMemcpy(fl.data(), b->mem + b->lay.flags, (size_t)b->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
         return SUSHI_HIP_ELAUNCH;

@@ -587,7 +587,9 @@ void refine_kernel(RefineParams a) {
     const int s_idx = a.first_search + blockIdx.x;
     const SearchDesc sd = a.searches[s_idx];
     const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
-    if (tid == 0) { cnt = 0; ovf = 0; violated = 0; wg_ratio[0] = 0u; wg_ratio[1] = 0u; }
+    // (violated from the start: ifft_kernel found a pair of this search whose lower bound is above one of its real scores --
+    // the exclusion cannot be trusted for it, every position is evaluated)
+    if (tid == 0) { cnt = 0; ovf = 0; violated = (a.viol && a.viol[s_idx]) ? 1 : 0; wg_ratio[0] = 0u; wg_ratio[1] = 0u; }
     __syncthreads();
     // none: TM_CCOEFF_NORMED with every window uncertain -- then every listed position is a candidate
     const float U = a.gkeys[s_idx] == NO_KEY ? 4.0f : key_score(a.gkeys[s_idx]);
@@ -1057,7 +1059,7 @@ int sushi_hip_stream_create(const void* raw_dev, int dtype, int64_t n, int searc
     s->raw = raw_dev; s->dtype = dtype; s->n = n;
     s->xc = (float*)(m + l.xc); s->s1 = (double*)(m + l.s1); s->s2 = (double*)(m + l.s2);
     s->urel = (float*)(m + l.urel); s->usrel = (float*)(m + l.srel); s->base = (double*)(m + l.base); s->base_bytes = l.base_bytes;
-    s->spec = nullptr; s->spec_bytes = 0; s->blocks = nb; s->stats = s->base + 2 * (nb + 1);
+    s->spec = nullptr; s->spec_low = nullptr; s->znorm_rest = nullptr; s->norm_stride = 0; s->spec_bytes = 0; s->blocks = nb; s->stats = s->base + 2 * (nb + 1);
     s->coarse = (double*)(m + l.coarse); s->nc = n / COARSE_G + 2;
     hipStream_t st = (hipStream_t)hip_stream;
     double* bs2 = s->base;                       // block bases of sum x^2 (what the FFT path's scoring reads)
@@ -1107,6 +1109,8 @@ int sushi_hip_stream_view(const SushiHipStream* s, int which, const void** ptr_d
         case SUSHI_HIP_VIEW_UREL: *ptr_dev = s->urel; *bytes = (size_t)(s->n + 1) * sizeof(float); break;
         case SUSHI_HIP_VIEW_BASE: *ptr_dev = s->base; *bytes = (size_t)(s->blocks + 1) * sizeof(double); break;
         case SUSHI_HIP_VIEW_SPECTRA: *ptr_dev = s->spec; *bytes = s->spec_bytes; break;
+        case SUSHI_HIP_VIEW_SPECTRA_LOW: *ptr_dev = s->spec_low; *bytes = s->spec ? s->spec_bytes / 4 : 0; break;
+        case SUSHI_HIP_VIEW_ZNORM_REST: *ptr_dev = s->znorm_rest; *bytes = s->spec ? (size_t)3 * (size_t)s->norm_stride * sizeof(float) : 0; break;
         case SUSHI_HIP_VIEW_USREL: *ptr_dev = s->usrel; *bytes = (size_t)(s->n + 1) * 2 * sizeof(float); break;
         case SUSHI_HIP_VIEW_BASE1: *ptr_dev = s->base + (s->blocks + 1); *bytes = (size_t)(s->blocks + 1) * sizeof(double); break;
         case SUSHI_HIP_VIEW_COARSE: *ptr_dev = s->coarse; *bytes = (size_t)2 * (size_t)s->nc * sizeof(double); break;

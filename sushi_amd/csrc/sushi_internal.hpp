@@ -24,7 +24,11 @@ struct SushiHipStream {
                               //         totals): bound_kernel's lower bound of a block pair's window energies
     int64_t nc;
     size_t base_bytes;
-    void* spec;               // [(nb + 1) * N] complex f32 block spectra, or null
+    void* spec;               // [(nb + 1) * N] block spectra as packed halves, or null; behind them:
+    void* spec_low;           // [(nb + 1) * N / 4] the low band (|f| < N / 8) of every block spectrum again, in bound_low_kernel's order
+    float* znorm_rest;        // [3][norm_stride] norms over the bins OUTSIDE the band of a block spectrum's stored halves: of Z itself, of
+                              // the spectrum of its real block at j B, of the one at j B + H (sushi_fft.hip real_block_rest_norms)
+    int64_t norm_stride;
     size_t spec_bytes;
     int64_t blocks;           // nb
 };
@@ -70,6 +74,9 @@ struct RunCounters {
     uint32_t max_ratio_audit_bits;  // float bits of SushiHipBatchDiag.max_bound_ratio_noncandidate
     unsigned long long audited;     // non-candidate positions evaluated exactly (SushiHipBatchDiag.audited)
     unsigned long long pairs_transformed;   // block pairs whose inverse transform was run (the others were excluded by bound_kernel's bound)
+    unsigned long long excluded_audited;    // of those: pairs the bound HAD excluded, transformed as a check of the bound
+    uint32_t max_slb_ratio_bits;            // float bits: largest (lower bound / upper bound of the pair's real best score) over the audited excluded pairs
+    int32_t slb_violations;                 // pairs whose lower bound turned out above a real score (their searches go to every position)
 };
 
 int direct_variant_count();
@@ -98,6 +105,7 @@ struct RefineParams {
     RunCounters* counters;
     float delta;
     int method;                       // SUSHI_HIP_METHOD_*
+    const int* viol;                  // [all searches] or NULL: 1 = a pair's lower bound was found above a real score (ifft_kernel's audit)
 };
 int launch_refine(const RefineParams& p, hipStream_t st);
 

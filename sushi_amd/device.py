@@ -110,7 +110,7 @@ class DeviceStream(object):
                       "sushi_hip_stream_view")
         if not p.value:
             return None
-        owner = self._spec_mem if which == _native.VIEW_SPECTRA else self._mem
+        owner = self._spec_mem if which in (_native.VIEW_SPECTRA, _native.VIEW_SPECTRA_LOW, _native.VIEW_ZNORM_REST) else self._mem
         off = p.value - owner.data_ptr()
         return owner[off:off + nb.value].view(dtype)
 
@@ -161,7 +161,8 @@ class SearchBatch(object):
     (cv2.TM_CCOEFF_NORMED + argmax, the method BASELINE.json's wording names); both on either path.
 
     exclusion (FFT path) = 'auto' (default: the library excludes block pairs by a lower bound of their scores where a
-    sub-batch is large enough for that to pay), 'always', 'never' -- same results, different time; None reads
+    sub-batch is large enough for that to pay, in the form -- band-split or whole rows -- the streams' spectra allow), 'always'
+    (that choice of form for a batch of any size), 'never', 'band' / 'whole' (one form forced) -- same results, different time; None reads
     SUSHI_HIP_EXCLUSION (the GPU test suite sets it to 'always' so that every edge case goes through the exclusion).
     """
 
@@ -275,6 +276,7 @@ class SearchBatch(object):
                                                        flg.ctypes.data if per_search else None)
         _native.check(rc, "sushi_hip_batch_diagnostics")
         out = {k: getattr(d, k) for k, _ in _native.BatchDiag._fields_ if k != "reserved"}
+        out["band_votes"] = [int(v) for v in d.band_votes]
         if per_search:
             out["ranking_err"], out["flagged_per_search"] = err, flg
         return out

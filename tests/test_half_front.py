@@ -18,10 +18,15 @@ def test_packed_half_passes_equal_the_float32_passes_within_their_allowance():
     if not os.path.exists(EXE):
         pytest.skip("tools/ubench/half_front_check is not built (python -c 'import __graft_entry__ as g; g.build()')")
     out = subprocess.run([EXE], capture_output=True, text=True, timeout=120)
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    d = json.loads(lines[-1])
+    low = json.loads([l for l in lines if "low_max_abs_diff" in l][-1])
     assert out.returncode == 0, d
     assert d["non_finite"] == 0
     assert d["max_abs_diff"] <= d["bound_on_diff"]
     assert d["diff_over_max"] < 0.01                      # measured: 0.0011
     assert abs(d["max_abs_A_half"] - d["max_abs_A_f32"]) <= 0.005 * d["max_abs_A_f32"]
+    # the low-band group transform (bound_low_kernel) against a float64 DFT of the same 512 bins: layout, operands and passes
+    assert low["low_non_finite"] == 0
+    assert low["low_max_abs_diff"] <= low["low_bound_on_diff"]
+    assert low["low_diff_over_max"] < 0.01

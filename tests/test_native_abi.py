@@ -25,7 +25,7 @@ def test_library_builds_and_exports_all_declared_symbols():
 def test_host_only_entry_points():
     L = _native.lib()
     C = ctypes
-    assert L.sushi_hip_abi_version() == _native.ABI_VERSION == 9
+    assert L.sushi_hip_abi_version() == _native.ABI_VERSION == 10
     assert L.sushi_hip_strerror(0) == b"ok" and b"invalid" in L.sushi_hip_strerror(-1)
     assert L.sushi_hip_centre(_native.U8) == 128.0 and L.sushi_hip_centre(_native.F32) == 0.5
     N, B = L.sushi_hip_fft_size(), L.sushi_hip_fft_block()
@@ -34,7 +34,8 @@ def test_host_only_entry_points():
     assert L.sushi_hip_stream_bytes(0, 1, 0) == 0 and L.sushi_hip_stream_bytes(10, 7, 0) == 0
     plain, searchable = L.sushi_hip_stream_bytes(100000, _native.F32, 0), L.sushi_hip_stream_bytes(100000, _native.F32, 1)
     assert plain >= 100000 * 4 + 2 * 100001 * 8 + 100001 * 4 and plain % 256 == 0
-    assert L.sushi_hip_stream_spectra_bytes(4097) == 3 * N * 4 and L.sushi_hip_stream_spectra_bytes(0) == 0
+    # two blocks + the all-zero one: whole rows, the low-band rows (a quarter of the bins) and the rows' norms outside the band
+    assert L.sushi_hip_stream_spectra_bytes(4097) == 3 * N * 4 + 3 * N + 256 and L.sushi_hip_stream_spectra_bytes(0) == 0
     assert searchable - plain == (L.sushi_hip_stream_spectra_bytes(100000) + 255) // 256 * 256
     # argument validation happens before any HIP call
     h = C.c_void_p()

@@ -36,8 +36,9 @@ def _oracle(oracle, dst, src, off, m, ws, p, method="sqdiff_normed"):
     return k, float(row[k]), row
 
 
+@pytest.mark.parametrize("form", ["band", "whole", "always"])
 @pytest.mark.parametrize("method", ["sqdiff_normed", "ccoeff_normed"])
-def test_almost_every_pair_is_excluded_and_the_results_are_the_oracles(oracle, method):
+def test_almost_every_pair_is_excluded_and_the_results_are_the_oracles(oracle, method, form):
     n = 40 * PAIR
     dst = _stream(n, 1)
     rng = np.random.default_rng(2)
@@ -49,12 +50,22 @@ def test_almost_every_pair_is_excluded_and_the_results_are_the_oracles(oracle, m
         ws = a - int(rng.integers(PAIR, 4 * PAIR))
         p = 8 * PAIR + int(rng.integers(0, 5000))
         offs.append(a); lens.append(m); wst.append(ws); npos.append(min(p, n - ws - m + 1)); planted.append(a - ws)
-    idx, score, b = _run(dst, src, offs, lens, wst, npos, method)
+    idx, score, b = _run(dst, src, offs, lens, wst, npos, method, exclusion=form)
     d = b.diagnostics()
     assert d["all_positions"] == 0 and d["max_bound_ratio"] < 1.0 and d["max_bound_ratio_noncandidate"] < 1.0
+    # the form: forced, or -- 'always' -- chosen from the streams' own norms outside the band: low-passed material takes the band-split form
+    if form == "always":
+        assert d["band_votes"][0] == b.fft_pairs and d["band"] == (1 if d["band_votes"][1] >= 0.9 * d["band_votes"][0] else 0), d
+    else:
+        assert d["band"] == {"band": 1, "whole": 0}[form], d
+    # the audit of the exclusion: per run one excluded pair of every search is transformed all the same and its lower bound held
+    # to what it really scores
+    assert d["slb_violations"] == 0 and d["excluded_audited"] >= len(offs) // 2 and 0.0 < d["max_slb_ratio_excluded"] < 1.0, d
     # one pair per search is transformed first; whatever else survives is a fraction of the rest
     assert b.fft_pairs >= 9 * len(offs)
-    assert len(offs) <= d["pairs_transformed"] <= b.fft_pairs // 3, (d["pairs_transformed"], b.fft_pairs)
+    # (windows of eight pairs: the pair transformed first is already an eighth; the band-split form's bound is the looser of the two)
+    most = b.fft_pairs // 2 if d["band"] == 1 else b.fft_pairs // 3
+    assert len(offs) <= d["pairs_transformed"] - d["excluded_audited"] <= most, (d["pairs_transformed"], b.fft_pairs)
     for k in range(len(offs)):
         ok, osc, row = _oracle(oracle, dst, src, offs[k], lens[k], wst[k], npos[k], method)
         assert int(idx[k]) == ok == planted[k]
@@ -159,10 +170,80 @@ def test_always_never_and_auto_give_the_same_results(method, dtype):
         ws = a - int(rng.integers(0, 2 * PAIR))
         offs.append(a); lens.append(m); wst.append(ws); npos.append(min(int(rng.integers(PAIR // 2, 6 * PAIR)), n - ws - m + 1))
     res = {}
-    for mode in ("always", "never", "auto"):
+    for mode in ("always", "never", "auto", "band", "whole"):
         idx, score, b = _run(dst, src, offs, lens, wst, npos, method, exclusion=mode)
-        res[mode] = (idx.copy(), score.copy().view(np.uint32), b.diagnostics()["pairs_transformed"], b.fft_pairs)
+        dg = b.diagnostics()
+        res[mode] = (idx.copy(), score.copy().view(np.uint32), dg["pairs_transformed"] - dg["excluded_audited"], b.fft_pairs)
     assert (res["always"][0] == res["never"][0]).all() and (res["always"][1] == res["never"][1]).all()
     assert (res["auto"][0] == res["never"][0]).all() and (res["auto"][1] == res["never"][1]).all()
     assert res["never"][2] == res["never"][3] == res["auto"][2]          # no exclusion: every pair transformed; auto = never at this size
     assert res["always"][2] < res["never"][2]
+    for mode in ("band", "whole"):
+        assert (res[mode][0] == res["never"][0]).all() and (res[mode][1] == res["never"][1]).all(), mode
+        assert res[mode][2] < res["never"][2]
+
+
+def _lb_bin_of(entry, j):
+    """fft_core.hpp lb_bin_of: the frequency bin at sub-position j of entry `entry` of a low row."""
+    g, g4, l = entry >> 7, (entry >> 5) & 3, entry & 31
+    kq, mm = l >> 4, l & 15
+    d2, d3 = 4 * g4 + (mm & 3), mm >> 2
+    d1 = kq + (0, 2, 12, 14)[j]
+    k = g + 8 * (64 * d1 + 4 * d2 + d3)
+    return k if k < 2048 else k + 8192
+
+
+def test_low_band_rows_and_row_norms_are_the_spectra_again():
+    """Behind the block spectra: the low band (bins f < N/8, f >= 7N/8) of every block once more, in the order the bound's
+    transform loads it -- the very same halves --, and the norm of each block's stored halves OUTSIDE the band."""
+    import torch
+    from sushi_amd import _native
+    from sushi_amd.device import DeviceStream
+    x = _stream(5 * 4096 + 777, 21)
+    d = DeviceStream(x)
+    L = _native.lib()
+    N = L.sushi_hip_fft_size()
+    full = d.spectra().cpu().numpy().view(np.uint32).reshape(-1, N)            # one word (re | im << 16) per stored slot
+    low = d._view(_native.VIEW_SPECTRA_LOW, torch.float16).cpu().numpy().view(np.uint32).reshape(-1, N // 4)
+    norms = d._view(_native.VIEW_ZNORM_REST, torch.float32).cpu().numpy().reshape(3, -1)
+    zn, an, bn = norms[0][:7], norms[1][:7], norms[2][:7]
+    slot = np.array([L.sushi_hip_fft_slot_of_bin(f) for f in range(N)])
+    assert low.shape[0] == full.shape[0] == 7
+    bins = np.array([[_lb_bin_of(e, j) for j in range(4)] for e in range(N // 16)]).reshape(-1)
+    assert sorted(bins.tolist()) == list(range(N // 8)) + list(range(7 * N // 8, N))
+    assert (low == full[:, slot[bins]]).all()
+    rest = np.setdiff1d(np.arange(N), bins)
+    halves = d.spectra().cpu().numpy().astype(np.float64).reshape(-1, N, 2)
+    Z = (halves[..., 0] + 1j * halves[..., 1])[:, slot]                          # natural bin order, as stored
+    ref = np.sqrt((np.abs(Z[:, rest]) ** 2).sum(axis=1))
+    assert (zn >= ref * (1 - 1e-6)).all() and (zn <= ref * (1 + 1e-4) + 1e-6).all()
+    assert zn[-1] == 0.0                                                          # the all-zero block
+    # ... and of the two real blocks a spectrum packs: A(f) = (Z(f) + conj Z(N - f)) / 2, B(f) = (Z(f) - conj Z(N - f)) / 2i
+    Zm = np.conj(Z[:, (-np.arange(N)) % N])
+    ra = np.sqrt((np.abs((Z + Zm)[:, rest] / 2) ** 2).sum(axis=1))
+    rb = np.sqrt((np.abs((Z - Zm)[:, rest] / 2) ** 2).sum(axis=1))
+    assert (an >= ra * (1 - 1e-6)).all() and (an <= ra * (1 + 1e-4) + 1e-6).all()
+    assert (bn >= rb * (1 - 1e-6)).all() and (bn <= rb * (1 + 1e-4) + 1e-6).all()
+    assert np.allclose(an ** 2 + bn ** 2, zn ** 2, rtol=1e-4, atol=1e-6)          # |A|^2 + |B|^2 = |Z|^2 over a symmetric set of bins
+
+
+def test_white_material_takes_the_whole_row_form_and_a_forced_band_form_is_still_right(oracle):
+    """White noise keeps three quarters of its energy outside the band: the norms alone already use up the bound's room, AUTO /
+    ALWAYS take the whole-row form; forcing the band-split form excludes little or nothing and changes no result."""
+    n = 16 * PAIR
+    rng = np.random.default_rng(31)
+    dst = rng.random(n, dtype=np.float32)
+    src = (dst + rng.standard_normal(n).astype(np.float32) * 0.02).clip(0, 1).astype(np.float32)
+    offs, lens, wst, npos = [3 * PAIR + 5, 7 * PAIR + 99], [30000, 14000], [PAIR, 4 * PAIR + 3], [8 * PAIR, 7 * PAIR]
+    res = {}
+    for mode in ("always", "band", "never"):
+        idx, score, b = _run(dst, src, offs, lens, wst, npos, exclusion=mode)
+        res[mode] = (idx.copy(), score.copy().view(np.uint32), b.diagnostics())
+    assert res["always"][2]["band"] == 0 and res["band"][2]["band"] == 1
+    assert res["always"][2]["band_votes"][1] < 0.9 * res["always"][2]["band_votes"][0]
+    for mode in ("always", "band"):
+        assert (res[mode][0] == res["never"][0]).all() and (res[mode][1] == res["never"][1]).all()
+        assert res[mode][2]["slb_violations"] == 0
+    for k in range(2):
+        ok, osc, _ = _oracle(oracle, dst, src, offs[k], lens[k], wst[k], npos[k])
+        assert int(res["band"][0][k]) == ok
