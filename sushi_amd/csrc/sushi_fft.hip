@@ -321,14 +321,14 @@ struct TspecArgs {
     const double* dst_stats;          // the searched stream's stats: [0] largest energy of a pair's span, [1] its centring constant
     int method;                       // SUSHI_HIP_METHOD_CCOEFF_NORMED: spectra of the pattern minus its own mean
     uint4* tspec_low;                 // [segments of the sub-batch][LROWE] the low band again, in bound_low_kernel's order
-    float* tnorm_rest;                // [segments of the sub-batch] norm of the stored halves outside the band
+    float* tnorm_rest;                // [segments of the sub-batch] SQUARED norm of the stored halves outside the band (accumulated: zero it first)
+    int dbg;                          // development only (SUSHI_HIP_TSPEC_DBG): 1 no low store, 2 no norm atomic, 4 no norm at all
 };
 
 template <typename T>
 __global__ __launch_bounds__(FT)
 void tspec_kernel(TspecArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    __shared__ float red[FT / 64];
     const int tid = threadIdx.x;
     const sushi_fft::Twiddles tw = sushi_fft::load_twiddles<FFT_LOGN, -1>(tid, twiddles());
     const int seg = a.sub_first_seg + blockIdx.x;
@@ -373,15 +373,24 @@ void tspec_kernel(TspecArgs a) {
     }
     sushi_fft::fft_split<FFT_LOGN, -1>(v, tid, lds, tw);
     const float sc = t_scale / (float)FN;
-    float rest2;
-    const uint4 low = low_entry_and_rest(v, sc, rest2);
+    float rest2 = 0.f;
+    uint4 low = uint4{0u, 0u, 0u, 0u};
+    if (!(a.dbg & 4)) low = low_entry_and_rest(v, sc, rest2);
     to_load_order(v, tid, lds);
     uint4* __restrict__ out = reinterpret_cast<uint4*>(a.tspec + (size_t)blockIdx.x * FN);
 #pragma unroll
     for (int u = 0; u < sushi_fft::PER / 4; ++u)
         out[sushi_fft::wslot_uint4(tid, u)] = uint4{pack_h2(v[4 * u].x * sc, v[4 * u].y * sc), pack_h2(v[4 * u + 1].x * sc, v[4 * u + 1].y * sc),
                                                     pack_h2(v[4 * u + 2].x * sc, v[4 * u + 2].y * sc), pack_h2(v[4 * u + 3].x * sc, v[4 * u + 3].y * sc)};
-    store_low_row(low, rest2, tid, lds, red, a.tspec_low + (size_t)blockIdx.x * LROWE, a.tnorm_rest + blockIdx.x);
+    // The low entry straight to its place (sixteen half-written lines per wave, all completed by this workgroup within
+    // microseconds) and the wave's share of the norm's SQUARE to the segment's accumulator (zeroed before the launch; slb_kernel
+    // takes the root): staging both through the LDS, as spectra_kernel does once per stream, cost this kernel -- which runs every
+    // step -- two barriers more and 0.6 ms of 1.0 at BASELINE configs[2].
+    if (!(a.dbg & 1)) a.tspec_low[(size_t)blockIdx.x * LROWE + sushi_fft::lslot_of_thread(tid)] = low;
+    if (!(a.dbg & 6)) {
+        const float w = wave_sum_shfl(rest2);
+        if ((tid & 63) == 0) atomicAdd(a.tnorm_rest + blockIdx.x, w);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -676,12 +685,23 @@ void mac_list_kernel(MacListArgs a) {
         for (int c0 = 0; c0 < lay.n_seg; c0 += MAC_SMAX_LONG) {
             sushi_mac::acc4 acc = sushi_mac::zero_acc();
             const int s_end = c0 + MAC_SMAX_LONG < lay.n_seg ? c0 + MAC_SMAX_LONG : lay.n_seg;
-            for (int s = c0; s < s_end; ++s) {
-                const long long jj = FFT_STEP * I + s;
-                const sushi_mac::h8 z = as_h8(zsp[(size_t)(jj < z_zero ? jj : z_zero) * ROWE]);
-                const sushi_mac::h8 u = as_h8(tsp[(size_t)s * ROWE]);
-                const sushi_mac::zrow zr = {z, sushi_mac::rot_mi(z)};
-                if (s == c0) acc = sushi_mac::mul4(u, zr); else sushi_mac::mac4(acc, u, zr);
+            // six segments at a time, all twelve loads requested before the first product (a segment past the end multiplies a
+            // zero pattern entry: the sum is unchanged, as in the padded classes of mac_kernel)
+            for (int s6 = c0; s6 < s_end; s6 += 6) {
+                sushi_mac::h8 z[6], u[6];
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const int sx = s6 + t < s_end ? s6 + t : s_end - 1;
+                    const long long jj = FFT_STEP * I + sx;
+                    z[t] = as_h8(zsp[(size_t)(jj < z_zero ? jj : z_zero) * ROWE]);
+                    u[t] = as_h8(tsp[(size_t)sx * ROWE]);
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const sushi_mac::h8 ut = s6 + t < s_end ? u[t] : sushi_mac::zero_h8();
+                    const sushi_mac::zrow zr = {z[t], sushi_mac::rot_mi(z[t])};
+                    sushi_mac::mac4(acc, ut, zr);
+                }
             }
             unsigned o[sushi_mac::BINS];
 #pragma unroll
@@ -735,6 +755,8 @@ struct IfftArgs {
     const float* slb;                 // [pairs of the sub-batch] or NULL (no exclusion in this run)
     const unsigned char* audit_mark;  // [pairs of the sub-batch] 1 = the bound had EXCLUDED this pair (transformed as a check)
     int* viol;                        // [all searches] set to 1 where a lower bound turns out above a real score
+    int list_first;                   // with `count`: the first list slot this launch takes ...
+    int list_direct;                  // ... one workgroup per slot (ifft_kernel), or a fixed grid striding from there on (ifft_list_kernel)
 };
 
 constexpr int GQ = 4;                      // positions per window-energy load group
@@ -1107,19 +1129,20 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return __float_as_uint(wave_reduce_f32(__uint_as_float(v), [](float a, float b) { return __uint_as_float(__float_as_uint(a) > __float_as_uint(b) ? __float_as_uint(a) : __float_as_uint(b)); }));
 }
 
+// shared state of one pair's epilogue (ifft_kernel)
+struct IfftShared {
+    unsigned red_min, red_rs;        // float bits (both >= 0: unsigned order == float order)
+    float red_q[FT / 64];            // per wave: energy of its share of the Y row
+    int ccnt, unc_any;
+};
+
 template <int METHOD>
-__global__ __launch_bounds__(FT, 8)
-void ifft_kernel(IfftArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    __shared__ unsigned red_min, red_rs;        // float bits (both >= 0: unsigned order == float order)
-    __shared__ float red_q[FT / 64];            // per wave: energy of its share of the Y row
-    __shared__ int ccnt, unc_any;
-    const int tid = threadIdx.x;
-    if (a.count && (int)blockIdx.x >= *a.count) return;               // a list shorter than the grid (the pairs bound_kernel left)
+__device__ __forceinline__ void ifft_one(const IfftArgs& a, const int slot, float* lds, IfftShared& sh, const int tid) {
+    unsigned& red_min = sh.red_min; unsigned& red_rs = sh.red_rs; float (&red_q)[FT / 64] = sh.red_q; int& ccnt = sh.ccnt; int& unc_any = sh.unc_any;
     // which pair: by default the workgroup index; with a schedule the pairs that read the same region of the
     // destination stream run back to back on one XCD, so that the prefix-sum lines they share are fetched into that
     // XCD's L2 once instead of once per search
-    const int pr = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    const int pr = a.order ? a.order[slot] : slot;
     sushi_fft::uint4v yl[4];
     const float q2 = load_y(yl, a.y + (size_t)pr * (FN / 2), tid);     // in flight while the descriptors below arrive
     const sushi_fft::MfmaB mb = dft16_operands(tid);
@@ -1174,7 +1197,9 @@ void ifft_kernel(IfftArgs a) {
             // The pair's lower bound (slb_kernel) must not be above any of its exact scores, and the exact score of its best position
             // is at most lmin_s + e_pair.  Checked on every pair that IS transformed -- among them, per run, one pair per audited
             // search that the bound had excluded (survivor_kernel): where it fails the search is evaluated at every position.
-            const float s = a.slb[pr], ub = lmin_s + e_pair;
+            // (TM_SQDIFF_NORMED scores are clamped at 1, cv2's rule, the bound is not: a pair far louder than the pattern has
+            // a bound in the thousands and every score 1)
+            const float s = METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED ? a.slb[pr] : fminf(a.slb[pr], 1.0f), ub = lmin_s + e_pair;
             const bool audit = a.audit_mark && a.audit_mark[pr];
             if (s > ub * 1.00001f + 1e-7f) {
                 a.viol[a.first_search + k] = 1;
@@ -1235,6 +1260,32 @@ void ifft_kernel(IfftArgs a) {
     }
 }
 
+// One workgroup per pair; with `count` (a list whose length only the device knows: the pairs the bound left) a FIXED grid strides
+// over the list instead of one workgroup per possible entry -- 346,000 workgroups that found their slot empty were 0.3 ms of a step.
+template <int METHOD>
+__global__ __launch_bounds__(FT, 8)
+void ifft_kernel(IfftArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ IfftShared sh;
+    if (a.count && (int)blockIdx.x >= *a.count) return;               // a list shorter than the grid
+    ifft_one<METHOD>(a, (int)blockIdx.x, lds, sh, (int)threadIdx.x);
+}
+template <int METHOD>
+__global__ __launch_bounds__(FT, 8)
+void ifft_list_kernel(IfftArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ IfftShared sh;
+    const int n = *a.count;
+    for (int slot = a.list_first + blockIdx.x; slot < n; slot += gridDim.x) {
+        // (everything an iteration needs is loaded inside it, off a thread index the compiler cannot see through: left to hoist
+        // the transform's per-thread constants out of the loop it spills them -- collect_kernel's lesson)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        ifft_one<METHOD>(a, slot, lds, sh, tid);
+        __syncthreads();                                               // the shared state is consumed before the next pair resets it
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Which block pairs need no inverse transform at all.
 //
@@ -1285,7 +1336,7 @@ struct BoundArgs {
     // band-split form (bound_low_kernel: `y` = the low rows; slb_kernel adds the rest of the spectrum from the rows' norms)
     int band;                         // 0: `acc` is over whole rows (bound_kernel); 1: over low rows + norms; 2: norms only (prediction)
     int sub_first_seg;
-    const float* tnorm_rest;          // [segments of the sub-batch] pattern spectra: norm outside the band
+    const float* tnorm_rest;          // [segments of the sub-batch] pattern spectra: SQUARED norm outside the band
     const float* znorm_rest;          // [3][norm_stride] block spectra: norm outside the band of Z, of its real block at j B, of the one H on
     int64_t norm_stride;
     int* band_votes;                  // [2] prediction: pairs looked at, pairs whose bound leaves room
@@ -1453,7 +1504,7 @@ __global__ __launch_bounds__(256)
 void slb_kernel(BoundArgs a) {
     constexpr bool CC = METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED;
     const int lane = threadIdx.x & 63;
-    const int pr = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int pr = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (pr >= a.n_pairs) return;
     const int k = __builtin_amdgcn_readfirstlane(a.pairmap[pr]);
     const SearchDesc sd = a.searches[k];
@@ -1466,67 +1517,89 @@ void slb_kernel(BoundArgs a) {
     const int n_seg = lay.n_seg;
     const int64_t n = a.dst_len;
     const double c = a.dst_stats[1];
+    // A wave is a chain of dependent look-ups (pair -> search -> constants -> tables), 354,555 of them at BASELINE configs[2]: what
+    // it costs is round trips, not instructions.  So EVERYTHING the wave will read is requested here in one flight, raw, and used
+    // only after the table look-ups have been requested too.
+    const float acc0 = a.acc[2 * (size_t)pr], acc1 = a.acc[2 * (size_t)pr + 1];
+    const int64_t iA = kA < a.nb ? kA : a.nb, iB = kA + n_seg + 2 * FFT_VB < a.nb ? kA + n_seg + 2 * FFT_VB : a.nb;
+    const double u0 = a.ubase[iA], u1 = a.ubase[iB], s0 = a.sbase[iA], s1 = a.sbase[iB];
+    // band-split form: what the bins outside the band can add to any output of the pair's transform, from the norms of the rows
+    // that meet (Cauchy-Schwarz per segment, the triangle inequality over the segments; the stored halves' own rounding and
+    // their subnormal floor on top; a pattern of more than MAC_SMAX_LONG segments re-rounds its partial row once per pass).
+    // The real parts of the pair's outputs meet the real blocks at 6 I + s, the imaginary parts those H samples on: each from
+    // its own block's norm (real_block_rest_norms) -- the larger of the two sums bounds both parts.  That split assumes the
+    // pattern rows conjugate-symmetric (spectra of real segments); what their stored halves lack of it (half an ulp per bin
+    // and the float32 transform's own asymmetry: < 1.5e-3 of a row's norm) meets the whole |Z|.
+    // (unconditional loads from clamped places -- a branch around them would be a second flight --, masked afterwards)
+    const int sl = lane < n_seg ? lane : 0;
+    const int64_t jl = kA + sl < a.nb ? kA + sl : a.nb;
+    float tn0 = a.tnorm_rest[(sd.first_seg - a.sub_first_seg) + sl];
+    const float zn0 = a.znorm_rest[jl], an0 = a.znorm_rest[a.norm_stride + jl], bn0 = a.znorm_rest[2 * a.norm_stride + jl];
     // lower bound of the window energies (variance sums): the stretches of COARSE_G positions that hold a valid position
     constexpr int NSB = 2 * FH / COARSE_G;
     static_assert(NSB <= 128 && (FFT_STEP * FFT_SEG) % COARSE_G == 0, "a lane looks up two stretches");
     const int64_t plo = sd.win_start - qbase, phi = (int64_t)sd.n_pos + (sd.win_start - qbase);       // valid: plo <= pos < phi
     const double* __restrict__ c2 = a.coarse;
     const double* __restrict__ c1 = a.coarse + a.nc;
-    float wl = __builtin_inff();
+    auto clampi = [&](int64_t x) { return x < a.nc - 1 ? x : a.nc - 1; };
+    // (both stretches of a lane: unconditional loads from clamped places, the stretch's validity applied afterwards)
+    bool use[2];
+    int64_t js[2], je[2], jo0[2], jo1[2];
+    double c2e[2], c2s[2], c1e[2], c1s[2], c2o1[2], c2o0[2], c1o1[2], c1o0[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int sb = lane + 64 * t;
         const int64_t p0 = (int64_t)sb * COARSE_G;
-        if (sb < NSB && p0 + COARSE_G > plo && p0 < phi) {
-            const int64_t j = qbase / COARSE_G + sb;
-            auto clampi = [&](int64_t x) { return x < a.nc - 1 ? x : a.nc - 1; };
-            const int64_t js = clampi(j + 1), je = clampi(j + M / COARSE_G);
+        use[t] = sb < NSB && p0 + COARSE_G > plo && p0 < phi;
+        const int64_t j = qbase / COARSE_G + sb;
+        js[t] = clampi(j + 1); je[t] = clampi(j + M / COARSE_G);
+        c2e[t] = c2[je[t]]; c2s[t] = c2[js[t]];
+        if (CC) {
+            jo0[t] = clampi(j); jo1[t] = clampi(j + M / COARSE_G + 2);
+            c1e[t] = c1[je[t]]; c1s[t] = c1[js[t]];
+            c2o1[t] = c2[jo1[t]]; c2o0[t] = c2[jo0[t]]; c1o1[t] = c1[jo1[t]]; c1o0[t] = c1[jo0[t]];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);          // (nothing that uses a loaded value moves above this line: one flight)
+    float wl = __builtin_inff();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (use[t]) {
             double e = 0.0;
-            if (je > js) {
+            if (je[t] > js[t]) {
                 if (CC) {
                     auto len = [&](int64_t lo, int64_t hi) {
                         const int64_t x0 = lo * COARSE_G < n ? lo * COARSE_G : n, x1 = hi * COARSE_G < n ? hi * COARSE_G : n;
                         return (double)(x1 - x0);
                     };
-                    const int64_t jo0 = clampi(j), jo1 = clampi(j + M / COARSE_G + 2);
-                    const double d_in = (c1[je] - c1[js]) - c * len(js, je);
-                    const double e_in = (c2[je] - c2[js]) - 2.0 * c * (c1[je] - c1[js]) + c * c * len(js, je);
-                    const double e_out = (c2[jo1] - c2[jo0]) - 2.0 * c * (c1[jo1] - c1[jo0]) + c * c * len(jo0, jo1);
+                    const double d_in = (c1e[t] - c1s[t]) - c * len(js[t], je[t]);
+                    const double e_in = (c2e[t] - c2s[t]) - 2.0 * c * (c1e[t] - c1s[t]) + c * c * len(js[t], je[t]);
+                    const double e_out = (c2o1[t] - c2o0[t]) - 2.0 * c * (c1o1[t] - c1o0[t]) + c * c * len(jo0[t], jo1[t]);
                     const double d_ub = fabs(d_in) + sqrt(2.0 * COARSE_G * fmax(e_out - e_in, 0.0)) * 1.000001 + 1e-6 * (fabs(d_in) + 1.0);
-                    e = e_in * 0.999999 - d_ub * d_ub / (double)M - 1e-9 * (c2[je] - c2[js]);    // (the prefix table's own rounding)
+                    e = e_in * 0.999999 - d_ub * d_ub / (double)M - 1e-9 * (c2e[t] - c2s[t]);    // (the prefix table's own rounding)
                 } else {
-                    e = c2[je] - c2[js];
+                    e = c2e[t] - c2s[t];
                 }
             }
             wl = fminf(wl, fmaxf((float)e * 0.9999995f, 0.f));
         }
     }
     const float wlb = wave_min_f32(wl);
-    // band-split form: what the bins outside the band can add to any output of the pair's transform, from the norms of the rows
-    // that meet (Cauchy-Schwarz per segment, the triangle inequality over the segments; the stored halves' own rounding and
-    // their subnormal floor on top; a pattern of more than MAC_SMAX_LONG segments re-rounds its partial row once per pass)
     float b_rest = 0.f;
     if (a.band) {
-        // The real parts of the pair's outputs meet the real blocks at 6 I + s, the imaginary parts those H samples on: each from
-        // its own block's norm (real_block_rest_norms) -- the larger of the two sums bounds both parts.  That split assumes the
-        // pattern rows conjugate-symmetric (spectra of real segments); what their stored halves lack of it (half an ulp per bin
-        // and the float32 transform's own asymmetry: < 1.5e-3 of a row's norm) meets the whole |Z|.
-        const float* __restrict__ tn = a.tnorm_rest + (sd.first_seg - a.sub_first_seg);
-        const float* __restrict__ zn = a.znorm_rest;
-        const float* __restrict__ an = a.znorm_rest + a.norm_stride;
-        const float* __restrict__ bn = a.znorm_rest + 2 * a.norm_stride;
-        float pz = 0.f, pa = 0.f, pb = 0.f;
-        for (int s = lane; s < n_seg; s += 64) {
+        const float t0n = lane < n_seg ? sqrtf(tn0) * 1.000002f : 0.f;
+        float pz = t0n * zn0, pa = t0n * an0, pb = t0n * bn0;
+        for (int s = lane + 64; s < n_seg; s += 64) {               // (patterns of more than 64 segments)
             const int64_t jj = kA + s < a.nb ? kA + s : a.nb;
-            const float t = tn[s];
-            pz += t * zn[jj]; pa += t * an[jj]; pb += t * bn[jj];
+            const float t = sqrtf(a.tnorm_rest[(sd.first_seg - a.sub_first_seg) + s]) * 1.000002f;
+            pz += t * a.znorm_rest[jj]; pa += t * a.znorm_rest[a.norm_stride + jj]; pb += t * a.znorm_rest[2 * a.norm_stride + jj];
         }
         pz = wave_sum_f32(pz); pa = wave_sum_f32(pa); pb = wave_sum_f32(pb);
         const int passes = (n_seg + MAC_SMAX_LONG - 1) / MAC_SMAX_LONG;
         b_rest = (fmaxf(pa, pb) + 1.5e-3f * pz) * tc.mac_scale * (1.0006f + 0.0005f * (float)passes) + 1e-3f;
     }
     if (lane == 0) {
-        float B = a.acc[2 * (size_t)pr], qmax = a.acc[2 * (size_t)pr + 1];
+        float B = acc0, qmax = acc1;
         if (a.band) {
             // acc[1] is the low band's energy, and the rest's is at most the square of its sum of moduli -- as one sixteenth of a
             // row's energy, the unit the model below takes
@@ -1534,8 +1607,6 @@ void slb_kernel(BoundArgs a) {
             qmax = ((a.band == 2 ? 0.f : qmax) + b_rest * b_rest) * (1.0f / (float)(FT / 64));
         }
         // energy of the samples that enter this pair's transforms, as they are (zn) and centred (zn_c): score_pair's
-        const int64_t iA = kA < a.nb ? kA : a.nb, iB = kA + n_seg + 2 * FFT_VB < a.nb ? kA + n_seg + 2 * FFT_VB : a.nb;
-        const double u0 = a.ubase[iA], u1 = a.ubase[iB], s0 = a.sbase[iA], s1 = a.sbase[iB];
         const int64_t s_lo = qbase < n ? qbase : n;
         const int64_t s_hi64 = (kA + n_seg + 2 * FFT_VB) * (int64_t)FFT_SEG;
         const int64_t s_hi = s_hi64 < n ? s_hi64 : n;
@@ -2131,7 +2202,7 @@ int sushi_hip_batch_create(const SushiHipStream* dst, const SushiHipStream* src,
     std::unique_ptr<SushiHipBatch> guard(b);                     // freed on every early return and on an exception
     b->dst = dst; b->src = src; b->n = n; b->path = path; b->variant = variant; b->method = SUSHI_HIP_METHOD_SQDIFF_NORMED;
     b->exclusion = SUSHI_HIP_EXCLUDE_AUTO;
-    b->band = -1; b->last_band = -1; b->band_decided_method = -1; b->band_votes[0] = b->band_votes[1] = 0; b->run_seq = 0; b->audit_every = 1;
+    b->band = -1; b->last_band = -1; b->band_decided_method = -1; b->band_votes[0] = b->band_votes[1] = 0; b->run_seq = 0; b->audit_every = 2;
     {
         const char* e = getenv("SUSHI_HIP_AUDIT_EVERY");      // (measurements: 0 = no excluded pair is audited)
         if (e && *e) { const int v = atoi(e); b->audit_every = v < 0 ? 0 : v; }
@@ -2267,6 +2338,8 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         ta.tspec = tspec; ta.sub_first_pair = sbt.first_pair; ta.pairmap = pairmap; ta.tconst = tconst;
         ta.src_s1 = src->s1; ta.src_s2 = src->s2; ta.centre = r.centre; ta.dst_stats = dst->stats; ta.method = b->method;
         ta.tspec_low = tspec_low; ta.tnorm_rest = tnorm_rest;
+        { const char* e = getenv("SUSHI_HIP_TSPEC_DBG"); ta.dbg = e && *e ? atoi(e) : 0; }
+        if (hipMemsetAsync(tnorm_rest, 0, (size_t)sbt.segs * sizeof(float), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
         if (src->dtype == SUSHI_HIP_F32) hipLaunchKernelGGL(tspec_kernel<float>, dim3((unsigned)sbt.segs), dim3(FT), 0, st, ta);
         else hipLaunchKernelGGL(tspec_kernel<uint8_t>, dim3((unsigned)sbt.segs), dim3(FT), 0, st, ta);
         if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
@@ -2364,8 +2437,13 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         ia.cand_cap = (int)cand_capacity(sbt.pairs); ia.counters = counters;
         ia.viol = viol;
         auto launch_ifft = [&](const IfftArgs& x, unsigned grid) {
-            if (ccm) hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3(grid), dim3(FT), 0, st, x);
-            else hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3(grid), dim3(FT), 0, st, x);
+            if (x.count && !x.list_direct) {                         // a list whose length only the device knows: a fixed grid strides over its tail
+                if (ccm) hipLaunchKernelGGL(ifft_list_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3(grid), dim3(FT), 0, st, x);
+                else hipLaunchKernelGGL(ifft_list_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3(grid), dim3(FT), 0, st, x);
+            } else {
+                if (ccm) hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3(grid), dim3(FT), 0, st, x);
+                else hipLaunchKernelGGL(ifft_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3(grid), dim3(FT), 0, st, x);
+            }
             return launch_ok();
         };
         // the whole rows of LISTED pairs (band-split form: nothing but the low band exists until a pair is to be transformed)
@@ -2412,7 +2490,16 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             ip.order = ba.slist; ip.count = ba.scount; ip.audit_mark = ba.audit_mark;
             if (band && launch_mac_list(ba.slist, ba.scount, (int)sbt.pairs) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-            if (launch_ifft(ip, (unsigned)sbt.pairs) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            // One workgroup per list slot up to what the list usually holds (a sixteenth of the pairs: empty slots there cost a
+            // workgroup's launch each, ~1 ns), and a fixed grid striding over whatever lies beyond: the striding form alone runs
+            // at half the rate per pair (the loop costs it registers), one workgroup per POSSIBLE slot cost 0.3 ms of empty launches.
+            const unsigned direct = (unsigned)std::min<int64_t>(sbt.pairs, std::max<int64_t>(4096, sbt.pairs / 16));
+            ip.list_first = 0; ip.list_direct = 1;
+            if (launch_ifft(ip, direct) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            if ((int64_t)direct < sbt.pairs) {
+                ip.list_first = (int)direct; ip.list_direct = 0;
+                if (launch_ifft(ip, (unsigned)std::min<int64_t>(sbt.pairs - direct, 1024)) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            }
         }
         prof_end(pc, t0, SUSHI_HIP_STAGE_IFFT, st);
 

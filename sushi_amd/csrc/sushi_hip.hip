@@ -636,13 +636,17 @@ void refine_kernel(RefineParams a) {
                 if (rows[(size_t)pa * FFT_ROW + FFT_CAND + 1] != NO_KEY) sel[n_sel++] = pa;      // transformed: it left its error bound
             }
             bool wide = false;
-            if (n_sel == 1) {
-                // the four runs of one pair are sixteen consecutive positions: one task, the window loads of ONE position
+            if (n_sel >= 1) {
+                // the four runs of ONE pair are sixteen consecutive positions: one task, the window loads of ONE position -- a
+                // quarter of what four runs from four pairs cost (the pair is picked by the search's hash among the transformed
+                // ones: over the searches of a batch every kind of pair is looked at).  A pair at the window's edge may not hold
+                // all sixteen: then the runs are taken one by one, from as many pairs as there are.
+                const int pick = sel[(h >> 3) % (unsigned)n_sel];
                 wide = true;
-                for (int q = 0; q < RAUD; ++q) wide = wide && rows[(size_t)sel[0] * FFT_ROW + FFT_CAND + 2 + q] != NO_KEY;
+                for (int q = 0; q < RAUD; ++q) wide = wide && rows[(size_t)pick * FFT_ROW + FFT_CAND + 2 + q] != NO_KEY;
                 if (wide) {
                     tent[n_tasks] = (short)n_all; tlen[n_tasks] = RAUD; ++n_tasks;
-                    for (int q = 0; q < RAUD; ++q) { list[n_all] = rows[(size_t)sel[0] * FFT_ROW + FFT_CAND + 2 + q]; lpair[n_all] = sel[0]; ++n_all; }
+                    for (int q = 0; q < RAUD; ++q) { list[n_all] = rows[(size_t)pick * FFT_ROW + FFT_CAND + 2 + q]; lpair[n_all] = pick; ++n_all; }
                 }
             }
             for (int r = 0; r < AUDIT_RUNS && n_sel > 0 && !wide; ++r) {

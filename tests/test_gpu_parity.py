@@ -812,12 +812,12 @@ def test_one_accumulation_order_whatever_route_finds_the_position():
 def test_short_pattern_with_dozens_of_near_tie_candidates(oracle, dtype, M):
     """ADVICE r4 (refine_body): a pattern of at most 15 chunks of 512 samples gets more tasks per round than the round's
     finishing step has thread groups for.  A periodic stream gives ~39 candidates spread over several block pairs (at most 8
-    per pair: none overflows), every copy but a LATE one off by one quantum in one sample: the exact minimum is that late
+    per pair: none overflows), every copy but a LATE one off in one sample: the exact minimum is that late
     copy, and every candidate has to be finished for it to be found."""
     rng = np.random.default_rng(4242 + M)
-    period, reps, best = 4000, 40, 30
+    period, reps, best = 9000, 40, 30                 # longer than every pattern here: a window meets one copy's quantum only
     if dtype == np.uint8:
-        base = rng.integers(1, 255, period, dtype=np.uint8)
+        base = rng.integers(1, 239, period, dtype=np.uint8)
     else:
         base = (0.1 + 0.7 * rng.random(period, dtype=np.float32)).astype(np.float32)
     dst = np.tile(base, reps)
@@ -825,9 +825,9 @@ def test_short_pattern_with_dozens_of_near_tie_candidates(oracle, dtype, M):
     for k in range(reps):
         if k != best:
             j = k * period + a + (37 * k) % M
-            # uint8: one quantum (exact arithmetic separates it); float32: enough to clear the float32 quantum of cv2's stored
-            # cross term (2.4e-7 in score) and stay inside the candidate margin (2e-5): a score of ~4e-6
-            dst[j] = dst[j] + (1 if dtype == np.uint8 else np.float32(np.sqrt(1.2e-6 * M)))
+            # enough to clear the float32 quantum of cv2's stored cross term (2.4e-7 in score; for uint8 streams sum T*I ~ M * 128^2
+            # has an ulp of up to 32) and stay inside the candidate margin (2e-5): a score of ~1e-6 .. 4e-6
+            dst[j] = dst[j] + (16 if dtype == np.uint8 else np.float32(np.sqrt(1.2e-6 * M)))
     tpl = np.tile(base, 3)[a:a + M].copy()
     P = dst.shape[0] - M + 1
     (idx, score), b = _run_batch(dst, tpl, [0], [M], [0], [P], "fft", want_batch=True)
