@@ -95,6 +95,9 @@ SUSHI_HIP_API int sushi_hip_fft_block(void);     /* B: samples per block = per p
 /* Where bin f (0 <= f < N) of a block spectrum sits inside its N stored complex values (4 bytes each): spectra are kept
  * in the order the inverse transform loads them (coalesced 16-byte loads), not in natural order.  -1 for an invalid bin. */
 SUSHI_HIP_API int sushi_hip_fft_slot_of_bin(int bin);
+/* The same for the low-band rows behind the spectra (bins f < N/8 and f >= 7N/8 only; N/4 complex values of 4 bytes per row):
+ * their order is the one the band-split bound's transform loads them in.  -1 for a bin outside the band. */
+SUSHI_HIP_API int sushi_hip_fft_low_slot_of_bin(int bin);
 SUSHI_HIP_API double sushi_hip_centre(int dtype);
 SUSHI_HIP_API size_t sushi_hip_stream_bytes(int64_t n, int dtype, int searchable);
 SUSHI_HIP_API size_t sushi_hip_stream_spectra_bytes(int64_t n);
@@ -166,6 +169,9 @@ typedef struct SushiHipBatchDiag {
                                  score of its best position); < 1 or the search went to all_positions */
     int32_t slb_violations;   /* transformed pairs (audited or not) whose lower bound was found above a real score: 0 */
     int32_t band;             /* form of the exclusion the last run used: 0 whole rows, 1 band-split, -1 none */
+    int32_t suspended;        /* 1: AUTO left the exclusion out of the last run -- an earlier run of this batch had excluded next to
+                                 nothing (searches without a match anywhere: no bound can help), so the passes that compute the bounds
+                                 would only be overhead; every 64th run looks again */
     int32_t band_votes[2];    /* what AUTO / ALWAYS decided the form from (first run of a batch): block pairs looked at, and those whose
                                  bound -- with nothing but the rows' norms outside the band -- already leaves room to exclude; the
                                  band-split form is taken when that is >= 90 % */

@@ -51,7 +51,7 @@ class BatchDiag(ctypes.Structure):
                 ("max_bound_ratio_noncandidate", ctypes.c_float), ("audited", ctypes.c_int64),
                 ("pairs_transformed", ctypes.c_int64), ("excluded_audited", ctypes.c_int64),
                 ("max_slb_ratio_excluded", ctypes.c_float), ("slb_violations", ctypes.c_int32), ("band", ctypes.c_int32),
-                ("band_votes", ctypes.c_int32 * 2)]
+                ("suspended", ctypes.c_int32), ("band_votes", ctypes.c_int32 * 2)]
 
 
 _lib = None
@@ -91,6 +91,8 @@ def lib():
     L.sushi_hip_fft_block.restype = ci
     L.sushi_hip_fft_slot_of_bin.restype = ci
     L.sushi_hip_fft_slot_of_bin.argtypes = [ci]
+    L.sushi_hip_fft_low_slot_of_bin.restype = ci
+    L.sushi_hip_fft_low_slot_of_bin.argtypes = [ci]
     L.sushi_hip_centre.restype = dbl
     L.sushi_hip_centre.argtypes = [ci]
     L.sushi_hip_stream_bytes.restype = sz

@@ -722,6 +722,16 @@ SUSHI_HHD int lb_bin_of(int entry, int j) {     // frequency bin (0 .. WN-1) of 
     const int k = g + 8 * m;                      // index on the N/2 grid
     return k < WN / 8 ? k : k + WN / 2;
 }
+// ... and the other way: where bin f sits in a low row, as entry * 4 + sub-position; -1 for a bin outside the band
+SUSHI_HHD int lslot_of_bin(int f) {
+    if (f < 0 || f >= WN || (f >= LB_HW && f < WN - LB_HW)) return -1;
+    const int k = f < LB_HW ? f : f - WN / 2;                     // index on the N/2 grid
+    const int g = k & 7, m = k >> 3;
+    const int d1 = m >> 6, d2 = (m >> 2) & 15, d3 = m & 3;
+    const int kq = d1 & 1, b = d1 - kq;                            // d1 = kq + {0, 2, 12, 14}
+    const int j = b == 0 ? 0 : (b == 2 ? 1 : (b == 12 ? 2 : 3));
+    return (((g * 4 + (d2 >> 2)) * 32 + 16 * kq + ((d3 << 2) | (d2 & 3))) << 2) + j;
+}
 // B operands of the K = 16 first pass (inverse transform, times 2^-10; high halves only): element j of lane l is row
 // k = 4 (l >> 4) + j of column n = l & 15.  form 0: real parts of the result, 1: imaginary parts.
 SUSHI_HHD double dft16_low_operand(int form, int l, int j) {

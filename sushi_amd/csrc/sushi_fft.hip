@@ -423,6 +423,7 @@ struct MacArgs {
     int sub_first_pair;
     int chunk_group;                  // bin chunks an XCD works on at a time (a power of two dividing its share)
     uint4* dummy;                     // [MAC_DUMMY_LINES][MAC_THREADS] where the stores of lanes without a valid output go
+    const int* enable;                // NULL, or a device flag: 0 = this launch is not needed (every workgroup leaves at once)
 };
 
 constexpr int MAC_DUMMY_LINES = 1024;
@@ -621,6 +622,7 @@ template <int RE>
 __global__ __launch_bounds__(MAC_THREADS, 3)
 void mac_kernel(MacArgs a) {
     __shared__ uint4 zring[MAC_WAVES][2][MAC_SMAX_SHORT + 1][2][MAC_BPW];   // per wave: two groups of rows, each with its rotation (+ a row nobody reads)
+    if (a.enable && *a.enable == 0) return;
     int item_idx, e0, slot, wave;
     mac_place<RE>(a, &item_idx, &e0, &slot, &wave);
     const int* __restrict__ item = a.items + (size_t)item_idx * (1 + MAC_SPW);
@@ -637,6 +639,7 @@ template <int RE>
 __global__ __launch_bounds__(MAC_THREADS, 2)
 void mac_long_kernel(MacArgs a) {
     __shared__ uint4 zring[MAC_WAVES][2][MAC_SMAX_LONG + 1][2][MAC_BPW];
+    if (a.enable && *a.enable == 0) return;
     int item_idx, e0, slot, wave;
     mac_place<RE>(a, &item_idx, &e0, &slot, &wave);
     const int* __restrict__ item = a.items + (size_t)item_idx * (1 + MAC_SPW);
@@ -663,12 +666,14 @@ struct MacListArgs {
     int n_list;                       // entries of `list` when count is NULL
     int sub_first_seg;
     int sub_first_pair;
+    const int* disable;               // NULL, or a device flag: 1 = the dense multiply-accumulate forms every row instead
 };
 constexpr int MACL_THREADS = 256;
 constexpr int MACL_PARTS = ROWE / MACL_THREADS;
 __global__ __launch_bounds__(MACL_THREADS)
 void mac_list_kernel(MacListArgs a) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    if (a.disable && *a.disable) return;
     const int n = a.count ? *a.count : a.n_list;
     const int z_zero = (int)(a.spec_blocks < 0x7fffffff ? a.spec_blocks : 0x7fffffff);
     for (long long it = blockIdx.x; it < (long long)n * MACL_PARTS; it += gridDim.x) {
@@ -1711,6 +1716,11 @@ void survivor_kernel(BoundArgs a) {
     if (keep) a.slist[base + __popcll(m & ((1ull << lane) - 1ull))] = pr;
 }
 
+// Band-split form, after survivor_kernel: forming whole rows pair by pair (mac_list_kernel, ~110 ns a pair) beats the dense
+// multiply-accumulate over ALL pairs only while few are listed -- a batch whose searches find no match excludes nothing.  dense[0]
+// = 1 hands the rows to mac_kernel's whole-row form instead (both launches are queued; the one not needed leaves at once).
+__global__ void dense_mode_kernel(const int* scount, int n_pairs, int* dense) { *dense = *scount > n_pairs / 5 ? 1 : 0; }
+
 // Collection pass over the flagged searches of a sub-batch: the same transforms and scores again (bit for bit), now
 // against the search's final threshold; every candidate goes to its tile's list, tiles with many candidates (or
 // when the buffer is full) are marked dense.  A fixed grid strides over the (search, pair) items refine_kernel listed.
@@ -1865,7 +1875,7 @@ inline WsLayout ws_layout(int64_t pairs, int64_t segs, int64_t searches) {
     w.acc = o; o += align_up((size_t)pairs * 2 * sizeof(float), 256);
     w.plist = o; o += align_up((size_t)searches * sizeof(int), 256);
     w.slist = o; o += align_up((size_t)pairs * sizeof(int), 256);
-    w.scount = o; o += 256;                                                      // [0] survivors, [1] collect items, [2..3] band prediction votes
+    w.scount = o; o += 256;                                                      // [0] survivors, [1] collect items, [2..3] band prediction votes, [4] dense whole rows
     w.citems = o; o += align_up((size_t)pairs * sizeof(int), 256);
     // band-split exclusion: low-band rows of the pattern spectra and of the products, the pattern rows' norms outside the band
     w.tspec_low = o; o += align_up((size_t)segs * LROW_BYTES, 256);
@@ -2106,6 +2116,15 @@ struct SushiHipBatch {
     unsigned run_seq;                   // runs so far: rotates which excluded pairs are audited
     int audit_every;                    // one search in this many has one excluded pair transformed as a check, per run
     int last_band;                      // form of the exclusion the last run's last sub-batch used (-1: none)
+    // AUTO learns from its own runs: a batch whose exclusion excluded next to nothing (searches without a match anywhere) runs
+    // without it from then on, looking again every 64th run.  The last run's counts come back through 16 bytes of pinned host memory
+    // behind an event that is only ever QUERIED: a run never waits for an earlier one.
+    unsigned long long* host_stats;     // [2] pairs transformed, excluded pairs audited
+    hipEvent_t stats_ready;
+    bool stats_pending;
+    int suspended;                      // 1: the exclusion is left out (AUTO)
+    unsigned suspended_at;              // run_seq of the run that showed it
+    int last_suspended;                 // whether the last run was one of those
     int64_t n_tiles;
     int64_t direct_pairs;               // pairs of the last run's sub-batches that were transformed without the exclusion
     std::vector<SearchDesc> descs;
@@ -2116,7 +2135,11 @@ struct SushiHipBatch {
     hipStream_t last_stream;
     bool ran;
     hipEvent_t uploaded;                // recorded on the create-time stream behind the descriptor / plan uploads
-    ~SushiHipBatch() { if (uploaded) (void)hipEventDestroy(uploaded); }
+    ~SushiHipBatch() {
+        if (uploaded) (void)hipEventDestroy(uploaded);
+        if (stats_ready) (void)hipEventDestroy(stats_ready);
+        if (host_stats) (void)hipHostFree(host_stats);
+    }
 };
 
 extern "C" {
@@ -2126,6 +2149,8 @@ int sushi_hip_fft_size(void) { return FN; }
 int sushi_hip_fft_block(void) { return FFT_SEG; }
 
 int sushi_hip_fft_slot_of_bin(int bin) { return (bin < 0 || bin >= FN) ? -1 : sushi_fft::mslot_of_bin(bin); }
+
+int sushi_hip_fft_low_slot_of_bin(int bin) { return sushi_fft::lslot_of_bin(bin); }
 
 size_t sushi_hip_stream_spectra_bytes(int64_t n) {
     if (n <= 0) return 0;
@@ -2202,6 +2227,7 @@ int sushi_hip_batch_create(const SushiHipStream* dst, const SushiHipStream* src,
     std::unique_ptr<SushiHipBatch> guard(b);                     // freed on every early return and on an exception
     b->dst = dst; b->src = src; b->n = n; b->path = path; b->variant = variant; b->method = SUSHI_HIP_METHOD_SQDIFF_NORMED;
     b->exclusion = SUSHI_HIP_EXCLUDE_AUTO;
+    b->host_stats = nullptr; b->stats_ready = nullptr; b->stats_pending = false; b->suspended = 0; b->suspended_at = 0; b->last_suspended = 0;
     b->band = -1; b->last_band = -1; b->band_decided_method = -1; b->band_votes[0] = b->band_votes[1] = 0; b->run_seq = 0; b->audit_every = 2;
     {
         const char* e = getenv("SUSHI_HIP_AUDIT_EVERY");      // (measurements: 0 = no excluded pair is audited)
@@ -2312,6 +2338,16 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
     if (hipMemsetAsync(viol, 0, (size_t)n_search * sizeof(int32_t), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
     const unsigned run_seq = b->run_seq++;
     const bool ccm = b->method == SUSHI_HIP_METHOD_CCOEFF_NORMED;
+    if (b->stats_pending && hipEventQuery(b->stats_ready) == hipSuccess) {
+        b->stats_pending = false;
+        const unsigned long long left = b->host_stats[0] - b->host_stats[1];
+        if ((double)left > 0.5 * (double)b->plan.pairs) { if (!b->suspended) b->suspended_at = run_seq; b->suspended = 1; }
+        else b->suspended = 0;
+    }
+    // (suspended: every 64th run looks again)
+    const bool suspended_now = b->exclusion == SUSHI_HIP_EXCLUDE_AUTO && b->suspended && ((run_seq - b->suspended_at) & 63u) != 63u;
+    b->last_suspended = suspended_now ? 1 : 0;
+    bool excluded_any = false;
 
     // (A two-stream variant that overlapped the multiply-accumulate of sub-batch n+1 with the inverse
     // transforms of sub-batch n was measured 5 % slower: both kernels only contend.)
@@ -2349,7 +2385,8 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         // it pays from ~3000 pairs on, plus two per search (the pairs transformed first are transformed either way).
         const bool exclude = b->exclusion == SUSHI_HIP_EXCLUDE_ALWAYS || b->exclusion == SUSHI_HIP_EXCLUDE_BAND ||
                              b->exclusion == SUSHI_HIP_EXCLUDE_WHOLE ||
-                             (b->exclusion == SUSHI_HIP_EXCLUDE_AUTO && sbt.pairs > 3000 + 2 * (int64_t)n_sub);
+                             (b->exclusion == SUSHI_HIP_EXCLUDE_AUTO && !suspended_now && sbt.pairs > 3000 + 2 * (int64_t)n_sub);
+        excluded_any = excluded_any || exclude;
         BoundArgs ba;
         memset(&ba, 0, sizeof(ba));
         ba.dst_stats = dst->stats; ba.searches = searches_dev + sbt.a0; ba.sub_first_pair = sbt.first_pair;
@@ -2394,23 +2431,25 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             b->last_band = band;
         }
 
-        t0 = prof_begin(pc, st);
-        {
+        // the multiply-accumulate over ALL pairs: of the low rows (band-split form) or of whole rows; `enable`: a device flag that
+        // may call the launch off (the whole-row launch queued behind the survivors' list, below)
+        auto launch_mac = [&](const bool low, const int* enable) {
             MacArgs ma;
             ma.spec_blocks = dst->blocks;
             ma.searches = searches_dev + sbt.a0; ma.tconst = tconst; ma.sub_first_seg = sbt.first_seg;
             ma.sub_first_pair = sbt.first_pair;
             ma.dummy = (uint4*)(wsp + wl.dummy);
-            if (band) { ma.spec = (const uint4*)dst->spec_low; ma.tspec = tspec_low; ma.y = ylow; }
+            ma.enable = enable;
+            if (low) { ma.spec = (const uint4*)dst->spec_low; ma.tspec = tspec_low; ma.y = ylow; }
             else { ma.spec = (const uint4*)dst->spec; ma.tspec = (const uint4*)tspec; ma.y = y; }
             for (int kern = 0; kern < 2; ++kern) {
                 if (sbt.item_count[kern] == 0) continue;
                 ma.items = items + (size_t)sbt.item_first[kern] * (1 + MAC_SPW);
                 ma.n_items = sbt.item_count[kern];
-                const int chunks = (band ? LROWE : ROWE) / MAC_BW;
+                const int chunks = (low ? LROWE : ROWE) / MAC_BW;
                 ma.chunk_group = std::min(sbt.chunk_group[kern], chunks / 8);
                 const dim3 grid((unsigned)chunks * (unsigned)ma.n_items);
-                if (band) {
+                if (low) {
                     if (kern == 0) hipLaunchKernelGGL(mac_kernel<LROWE>, grid, dim3(MAC_THREADS), 0, st, ma);
                     else hipLaunchKernelGGL(mac_long_kernel<LROWE>, grid, dim3(MAC_THREADS), 0, st, ma);
                 } else {
@@ -2419,7 +2458,10 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
                 }
                 if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             }
-        }
+            return SUSHI_HIP_OK;
+        };
+        t0 = prof_begin(pc, st);
+        if (launch_mac(band != 0, nullptr) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
         prof_end(pc, t0, SUSHI_HIP_STAGE_MAC, st);
 
         t0 = prof_begin(pc, st);
@@ -2447,8 +2489,9 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             return launch_ok();
         };
         // the whole rows of LISTED pairs (band-split form: nothing but the low band exists until a pair is to be transformed)
-        auto launch_mac_list = [&](const int* list, const int* count, int n_list) {
+        auto launch_mac_list = [&](const int* list, const int* count, int n_list, const int* disable) {
             MacListArgs la;
+            la.disable = disable;
             la.spec = (const uint4*)dst->spec; la.spec_blocks = dst->blocks; la.tspec = (const uint4*)tspec; la.y = y;
             la.searches = searches_dev + sbt.a0; la.tconst = tconst; la.pairmap = pairmap; la.list = list; la.count = count;
             la.n_list = n_list; la.sub_first_seg = sbt.first_seg; la.sub_first_pair = sbt.first_pair;
@@ -2484,12 +2527,20 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             IfftArgs ip = ia;
             ip.slb = ba.slb; ip.audit_mark = nullptr;              // (the pairs transformed first are nobody's excluded pairs)
             ip.order = ba.plist; ip.count = nullptr;
-            if (band && launch_mac_list(ba.plist, nullptr, n_sub) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            if (band && launch_mac_list(ba.plist, nullptr, n_sub, nullptr) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             if (launch_ifft(ip, (unsigned)n_sub) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             hipLaunchKernelGGL(survivor_kernel, dim3((unsigned)((sbt.pairs + 255) / 256)), dim3(256), 0, st, ba);
             if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             ip.order = ba.slist; ip.count = ba.scount; ip.audit_mark = ba.audit_mark;
-            if (band && launch_mac_list(ba.slist, ba.scount, (int)sbt.pairs) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            if (band) {
+                // whole rows of what is left: pair by pair while few are (the usual case), by the dense multiply-accumulate over all
+                // pairs when the bound excluded little (searches without a match: nothing can be excluded) -- decided on the device
+                int* dense = scount + 4;
+                hipLaunchKernelGGL(dense_mode_kernel, dim3(1), dim3(1), 0, st, (const int*)ba.scount, (int)sbt.pairs, dense);
+                if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+                if (launch_mac_list(ba.slist, ba.scount, (int)sbt.pairs, dense) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+                if (launch_mac(false, dense) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            }
             // One workgroup per list slot up to what the list usually holds (a sixteenth of the pairs: empty slots there cost a
             // workgroup's launch each, ~1 ns), and a fixed grid striding over whatever lies beyond: the striding form alone runs
             // at half the rate per pair (the loop costs it registers), one workgroup per POSSIBLE slot cost 0.3 ms of empty launches.
@@ -2533,6 +2584,15 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
     hipEvent_t t0 = prof_begin(pc, st);
     const int rc = launch_unpack(keys, n_search, b->method, out_idx_dev, out_score_dev, st);
     prof_end(pc, t0, SUSHI_HIP_STAGE_FINISH, st);
+    if (rc == SUSHI_HIP_OK && excluded_any && b->exclusion == SUSHI_HIP_EXCLUDE_AUTO && !b->stats_pending) {
+        // what this run's exclusion left, for the runs after it (never waited for: the event is queried)
+        if (!b->host_stats && hipHostMalloc((void**)&b->host_stats, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) b->host_stats = nullptr;
+        if (b->host_stats && !b->stats_ready && hipEventCreateWithFlags(&b->stats_ready, hipEventDisableTiming) != hipSuccess) b->stats_ready = nullptr;
+        if (b->host_stats && b->stats_ready &&
+            hipMemcpyAsync(b->host_stats, &counters->pairs_transformed, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) == hipSuccess &&
+            hipEventRecord(b->stats_ready, st) == hipSuccess)
+            b->stats_pending = true;
+    }
     return rc;
 } catch (...) { return SUSHI_HIP_ENOSPACE; }        // std::bad_alloc etc.: nothing crosses the C boundary
 
@@ -2558,6 +2618,7 @@ int sushi_hip_batch_diagnostics(SushiHipBatch* b, SushiHipBatchDiag* diag, float
     memcpy(&diag->max_slb_ratio_excluded, &c.max_slb_ratio_bits, sizeof(float));
     diag->slb_violations = c.slb_violations;
     diag->band = b->last_band;
+    diag->suspended = b->last_suspended;
     diag->band_votes[0] = b->band_votes[0]; diag->band_votes[1] = b->band_votes[1];
     std::vector<int32_t> fl((size_t)b->n);
     if (hipMemcpy(fl.data(), b->mem + b->lay.flags, (size_t)b->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)

@@ -583,6 +583,8 @@ void refine_kernel(RefineParams a) {
     __shared__ double part[RAUD * REFINE_THREADS];
     __shared__ int cnt, ovf, violated, n_all_s, n_tasks_s;
     __shared__ unsigned wg_ratio[2];             // this search's largest error / bound ratios (float bits): candidates, audit
+    constexpr int TMASK_PAIRS = 2048;            // which of the search's first 2048 pairs were transformed (the audit picks among them)
+    __shared__ unsigned tmask[TMASK_PAIRS / 32];
     const int tid = threadIdx.x;
     const int s_idx = a.first_search + blockIdx.x;
     const SearchDesc sd = a.searches[s_idx];
@@ -590,12 +592,16 @@ void refine_kernel(RefineParams a) {
     // (violated from the start: ifft_kernel found a pair of this search whose lower bound is above one of its real scores --
     // the exclusion cannot be trusted for it, every position is evaluated)
     if (tid == 0) { cnt = 0; ovf = 0; violated = (a.viol && a.viol[s_idx]) ? 1 : 0; wg_ratio[0] = 0u; wg_ratio[1] = 0u; }
+    if (tid < TMASK_PAIRS / 32) tmask[tid] = 0u;
     __syncthreads();
     // none: TM_CCOEFF_NORMED with every window uncertain -- then every listed position is a candidate
     const float U = a.gkeys[s_idx] == NO_KEY ? 4.0f : key_score(a.gkeys[s_idx]);
     const unsigned long long* __restrict__ rows = a.cand + (size_t)(sd.first_pair - a.sub_first_pair) * FFT_ROW;
     const float* __restrict__ plb = a.pair_lb + (sd.first_pair - a.sub_first_pair);
     for (int i = tid; i < lay.n_pairs; i += REFINE_THREADS) {
+        // (a transformed pair left its error bound: noted here, by every thread for its own pairs, for the audit's choice below --
+        // one thread walking the rows one dependent load at a time was a seventh of this kernel)
+        if (i < TMASK_PAIRS && rows[(size_t)i * FFT_ROW + FFT_CAND + 1] != NO_KEY) atomicOr(&tmask[i >> 5], 1u << (i & 31));
         if (!(plb[i] <= U)) continue;                         // no position of this pair can be the extremum
         for (int slot = 0; slot <= FFT_CAND; ++slot) {          // (slots behind FFT_CAND: the pair's error bound / audit run)
             const unsigned long long key = rows[(size_t)i * FFT_ROW + slot];
@@ -633,7 +639,8 @@ void refine_kernel(RefineParams a) {
             int sel[AUDIT_RUNS], n_sel = 0;
             for (int j = 0; j < lay.n_pairs && n_sel < AUDIT_RUNS; ++j) {
                 const int pa = pa0 + j < lay.n_pairs ? pa0 + j : pa0 + j - lay.n_pairs;
-                if (rows[(size_t)pa * FFT_ROW + FFT_CAND + 1] != NO_KEY) sel[n_sel++] = pa;      // transformed: it left its error bound
+                const bool tr = pa < TMASK_PAIRS ? ((tmask[pa >> 5] >> (pa & 31)) & 1u) != 0u : rows[(size_t)pa * FFT_ROW + FFT_CAND + 1] != NO_KEY;
+                if (tr) sel[n_sel++] = pa;                                  // transformed: it left its error bound
             }
             bool wide = false;
             if (n_sel >= 1) {

@@ -34,8 +34,8 @@ def test_host_only_entry_points():
     assert L.sushi_hip_stream_bytes(0, 1, 0) == 0 and L.sushi_hip_stream_bytes(10, 7, 0) == 0
     plain, searchable = L.sushi_hip_stream_bytes(100000, _native.F32, 0), L.sushi_hip_stream_bytes(100000, _native.F32, 1)
     assert plain >= 100000 * 4 + 2 * 100001 * 8 + 100001 * 4 and plain % 256 == 0
-    # two blocks + the all-zero one: whole rows, the low-band rows (a quarter of the bins) and the rows' norms outside the band
-    assert L.sushi_hip_stream_spectra_bytes(4097) == 3 * N * 4 + 3 * N + 256 and L.sushi_hip_stream_spectra_bytes(0) == 0
+    # two blocks + the all-zero one: whole rows, the low-band rows (a quarter of the bins) and three arrays of row norms outside the band
+    assert L.sushi_hip_stream_spectra_bytes(4097) == 3 * N * 4 + 3 * N + 3 * 256 and L.sushi_hip_stream_spectra_bytes(0) == 0
     assert searchable - plain == (L.sushi_hip_stream_spectra_bytes(100000) + 255) // 256 * 256
     # argument validation happens before any HIP call
     h = C.c_void_p()
@@ -60,6 +60,17 @@ def test_host_only_entry_points():
     assert pairs.value == (123456 + 2880000) // (6 * B) - 123456 // (6 * B) + 1
     assert L.sushi_hip_fft_layout(-1, 1, 1, C.byref(pairs), C.byref(segs)) == -1
     assert _native.fft_layout(4095, 4098, 36000) == (1, 9)
+    # the low-band rows: N/4 slots, every bin of the band (f < N/8, f >= 7N/8) exactly once, in the order the bound's transform
+    # loads it (fft_core.hpp "LOW BAND": entry = ((g * 4 + g4) * 32 + 16 kq + m'), sub-position j <-> d1 = kq + {0, 2, 12, 14}[j])
+    slots = [L.sushi_hip_fft_low_slot_of_bin(f) for f in range(N)]
+    band = [f for f in range(N) if f < N // 8 or f >= 7 * N // 8]
+    assert sorted(slots[f] for f in band) == list(range(N // 4)) and all(slots[f] == -1 for f in range(N // 8, 7 * N // 8))
+    for f in (0, 1, 8, 2047, N - 1, N - 2048, 777, N - 5):
+        e, j = divmod(slots[f], 4)
+        g, g4, l = e >> 7, (e >> 5) & 3, e & 31
+        kq, mm = l >> 4, l & 15
+        k = g + 8 * (64 * (kq + (0, 2, 12, 14)[j]) + 4 * (4 * g4 + (mm & 3)) + (mm >> 2))
+        assert (k if k < N // 8 else k + N // 2) == f
     # batch sizing: more workspace than one sub-batch needs is not taken; less cuts the batch, never below one request
     req = np.zeros(4, _native.REQUEST_DTYPE)
     req["win_start"] = [100000, 140000, 190000, 300000]

@@ -247,3 +247,38 @@ def test_white_material_takes_the_whole_row_form_and_a_forced_band_form_is_still
     for k in range(2):
         ok, osc, _ = _oracle(oracle, dst, src, offs[k], lens[k], wst[k], npos[k])
         assert int(res["band"][0][k]) == ok
+
+
+def test_nothing_to_exclude_dense_rows_then_auto_leaves_the_exclusion_out(oracle):
+    """Searches without a match anywhere (pattern and stream unrelated): no pair can be excluded.  A batch large enough for AUTO to
+    try: the first run finds that out the expensive way -- the band-split form then forms every whole row by the dense
+    multiply-accumulate instead of pair by pair --, the runs after it leave the exclusion out (diagnostics: suspended) until the
+    sixty-fourth looks again.  Same results every time, and the oracle's."""
+    import torch
+    n = 130 * PAIR
+    dst = _stream(n, 41)
+    src = _stream(60000, 42)
+    rng = np.random.default_rng(43)
+    offs, lens, wst, npos = [], [], [], []
+    for k in range(28):
+        m = int(rng.integers(12000, 40000))
+        offs.append(int(rng.integers(0, 60000 - m))); lens.append(m)
+        wst.append(int(rng.integers(0, 4 * PAIR))); npos.append(120 * PAIR)
+    from sushi_amd.device import DeviceStream, SearchBatch
+    b = SearchBatch(DeviceStream(dst), DeviceStream(src), offs, lens, wst, npos, path="fft", exclusion="auto")
+    assert b.fft_pairs > 3000 + 2 * len(offs)
+    runs = []
+    for r in range(3):
+        b.run()
+        torch.cuda.synchronize()
+        idx, score = b.results()
+        runs.append((idx.copy(), score.copy().view(np.uint32), b.diagnostics()))
+    d0, d1, d2 = runs[0][2], runs[1][2], runs[2][2]
+    assert d0["suspended"] == 0 and d0["band"] in (0, 1) and d0["pairs_transformed"] - d0["excluded_audited"] > 0.5 * b.fft_pairs
+    assert d1["suspended"] == 1 and d2["suspended"] == 1 and d1["pairs_transformed"] == b.fft_pairs and d1["band"] == -1
+    for r in (1, 2):
+        assert (runs[r][0] == runs[0][0]).all() and (runs[r][1] == runs[0][1]).all()
+    for k in (0, 13, 27):
+        ok, osc, row = _oracle(oracle, dst, src, offs[k], lens[k], wst[k], npos[k])
+        assert abs(float(runs[0][1].view(np.float32)[k]) - osc) <= 1e-4 * osc + 2.5e-7
+        assert int(runs[0][0][k]) == ok or abs(float(row[int(runs[0][0][k])]) - osc) <= 2.5e-7
