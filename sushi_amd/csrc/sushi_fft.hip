@@ -667,6 +667,7 @@ struct MacListArgs {
     int sub_first_seg;
     int sub_first_pair;
     const int* disable;               // NULL, or a device flag: 1 = the dense multiply-accumulate forms every row instead
+    int long_only;                    // 1: only pairs of patterns beyond MAC_SMAX_LONG segments (mac_rows_kernel forms the others)
 };
 constexpr int MACL_THREADS = 256;
 constexpr int MACL_PARTS = ROWE / MACL_THREADS;
@@ -682,6 +683,7 @@ void mac_list_kernel(MacListArgs a) {
         const int k = a.pairmap[pr];
         const SearchDesc sd = a.searches[k];
         const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
+        if (a.long_only && lay.n_seg <= MAC_SMAX_LONG) continue;
         const long long I = lay.pair0 + (a.sub_first_pair + pr - sd.first_pair);
         const float sy = a.tconst[k].mac_scale;
         const uint4* __restrict__ tsp = a.tspec + (size_t)(sd.first_seg - a.sub_first_seg) * ROWE + e;
@@ -758,7 +760,7 @@ struct IfftArgs {
     RunCounters* counters;
     // the audit of the exclusion: every transformed pair's lower bound against what the pair really scores
     const float* slb;                 // [pairs of the sub-batch] or NULL (no exclusion in this run)
-    const unsigned char* audit_mark;  // [pairs of the sub-batch] 1 = the bound had EXCLUDED this pair (transformed as a check)
+    const unsigned char* audit_mark;  // [pairs of the sub-batch] bit 0 = the bound had EXCLUDED this pair (transformed as a check)
     int* viol;                        // [all searches] set to 1 where a lower bound turns out above a real score
     int list_first;                   // with `count`: the first list slot this launch takes ...
     int list_direct;                  // ... one workgroup per slot (ifft_kernel), or a fixed grid striding from there on (ifft_list_kernel)
@@ -1205,7 +1207,7 @@ __device__ __forceinline__ void ifft_one(const IfftArgs& a, const int slot, floa
             // (TM_SQDIFF_NORMED scores are clamped at 1, cv2's rule, the bound is not: a pair far louder than the pattern has
             // a bound in the thousands and every score 1)
             const float s = METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED ? a.slb[pr] : fminf(a.slb[pr], 1.0f), ub = lmin_s + e_pair;
-            const bool audit = a.audit_mark && a.audit_mark[pr];
+            const bool audit = a.audit_mark && (a.audit_mark[pr] & 1);
             if (s > ub * 1.00001f + 1e-7f) {
                 a.viol[a.first_search + k] = 1;
                 atomicAdd(&a.counters->slb_violations, 1);
@@ -1345,7 +1347,7 @@ struct BoundArgs {
     const float* znorm_rest;          // [3][norm_stride] block spectra: norm outside the band of Z, of its real block at j B, of the one H on
     int64_t norm_stride;
     int* band_votes;                  // [2] prediction: pairs looked at, pairs whose bound leaves room
-    unsigned char* audit_mark;        // [pairs of the sub-batch] 1 = excluded, transformed all the same (the audit of the exclusion)
+    unsigned char* audit_mark;        // [pairs of the sub-batch] bit 0 = excluded, transformed all the same (the audit of the exclusion); bit 1 = listed
     unsigned audit_seq;               // changes from run to run: which excluded pair of a search is audited
     int audit_every;                  // one search in this many is audited per run (0: none)
 };
@@ -1703,7 +1705,7 @@ void survivor_kernel(BoundArgs a) {
             if (excluded && !audit) a.pair_lb[pr] = __builtin_inff();
             keep = !excluded || audit;
         }
-        if (a.audit_mark) a.audit_mark[pr] = audit ? 1 : 0;
+        if (a.audit_mark) a.audit_mark[pr] = (audit ? 1 : 0) | (keep ? 2 : 0);          // bit 0: audited, bit 1: listed
     }
     const unsigned long long m = __ballot(keep);
     const int lane = threadIdx.x & 63;
@@ -1714,6 +1716,100 @@ void survivor_kernel(BoundArgs a) {
     }
     base = __shfl(base, 0, 64);
     if (keep) a.slist[base + __popcll(m & ((1ull << lane) - 1ull))] = pr;
+}
+
+// The whole rows of the LISTED pairs, search by search (band-split form, the pairs the bound left): a workgroup = 256 consecutive
+// entries of ONE search; the pattern's segment spectra go to registers once and meet the block spectra of every listed pair of
+// that search in turn.  mac_list_kernel re-reads the pattern rows for every pair -- 0.6 MB a pair, 8.7 GB a step at BASELINE
+// configs[2], what that kernel's time is --; here they are read once per search (1.8 GB), and the block spectra of neighbouring
+// searches' pairs, walked at about the same time, meet in the L2.  Patterns of more than MAC_SMAX_LONG segments stay with
+// mac_list_kernel (`long_only` there).  Same sums in the same order as mac_kernel (a segment past the pattern's end is a zero entry).
+struct MacRowsArgs {
+    const uint4* spec;
+    int64_t spec_blocks;
+    const uint4* tspec;
+    uint4* y;
+    const SearchDesc* searches;
+    const TemplConsts* tconst;
+    const unsigned char* mark;        // [pairs of the sub-batch] bit 1: listed
+    int n_sub;
+    int sub_first_seg;
+    int sub_first_pair;
+    const int* disable;               // NULL, or a device flag: 1 = the dense multiply-accumulate forms every row instead
+};
+template <int SMAX>
+__device__ __forceinline__ void mac_rows_of_search(const MacRowsArgs& a, const SearchDesc& sd, const FftLayout& lay, const float sy,
+                                                   const int e, unsigned long long (*masks)[4], const int z_zero) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const uint4* __restrict__ tsp = a.tspec + (size_t)(sd.first_seg - a.sub_first_seg) * ROWE + e;
+    const uint4* __restrict__ zsp = a.spec + e;
+    const int p0 = sd.first_pair - a.sub_first_pair;
+    sushi_mac::h8 tt[SMAX];
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) tt[s] = s < lay.n_seg ? as_h8(tsp[(size_t)s * ROWE]) : sushi_mac::zero_h8();
+    const int tid = threadIdx.x;
+    for (int base = 0; base < lay.n_pairs; base += MACL_THREADS) {
+        // which of these 256 pairs are listed: one flag per thread, a ballot per wave
+        __syncthreads();
+        const int i = base + tid;
+        const bool on = i < lay.n_pairs && (a.mark[p0 + i] & 2);
+        const unsigned long long bm = __ballot(on);
+        if ((tid & 63) == 0) (*masks)[tid >> 6] = bm;
+        __syncthreads();
+        for (int w = 0; w < 4; ++w) {
+            unsigned long long m = (*masks)[w];
+            while (m) {
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1;
+                const int ip = base + 64 * w + bit;
+                const long long I = lay.pair0 + ip;
+                sushi_mac::acc4 acc = sushi_mac::zero_acc();
+#pragma unroll
+                for (int s6 = 0; s6 < SMAX; s6 += 6) {
+                    sushi_mac::h8 z[6];
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) {
+                        const long long jj = s6 + t < lay.n_seg ? FFT_STEP * I + s6 + t : (long long)z_zero;     // (past the pattern: the zero block)
+                        z[t] = as_h8(zsp[(size_t)(jj < z_zero ? jj : z_zero) * ROWE]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) {
+                        const sushi_mac::zrow zr = {z[t], sushi_mac::rot_mi(z[t])};
+                        sushi_mac::mac4(acc, tt[s6 + t], zr);
+                    }
+                }
+                unsigned o[sushi_mac::BINS];
+#pragma unroll
+                for (int q = 0; q < sushi_mac::BINS; ++q) {
+                    const h2 h = {(_Float16)(acc.re[q] * sy), (_Float16)(acc.im[q] * sy)};
+                    o[q] = __builtin_bit_cast(unsigned, h);
+                }
+                a.y[(size_t)(p0 + ip) * ROWE + e] = uint4{o[0], o[1], o[2], o[3]};
+            }
+        }
+    }
+}
+template <int LONG>            // 0: patterns of up to MAC_SMAX_SHORT segments; 1: longer ones up to MAC_SMAX_LONG (their registers halve the occupancy)
+__global__ __launch_bounds__(MACL_THREADS)
+void mac_rows_kernel(MacRowsArgs a) {
+    __shared__ unsigned long long masks[4];
+    if (a.disable && *a.disable) return;
+    const int z_zero = (int)(a.spec_blocks < 0x7fffffff ? a.spec_blocks : 0x7fffffff);
+    for (long long it = blockIdx.x; it < (long long)a.n_sub * MACL_PARTS; it += gridDim.x) {
+        const int k = (int)(it / MACL_PARTS);
+        const int e = (int)(it % MACL_PARTS) * MACL_THREADS + threadIdx.x;
+        const SearchDesc sd = a.searches[k];
+        const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
+        const float sy = a.tconst[k].mac_scale;
+        if (LONG) {
+            if (lay.n_seg > MAC_SMAX_SHORT && lay.n_seg <= MAC_SMAX_LONG) mac_rows_of_search<MAC_SMAX_LONG>(a, sd, lay, sy, e, &masks, z_zero);
+        } else {
+            if (lay.n_seg <= 6) mac_rows_of_search<6>(a, sd, lay, sy, e, &masks, z_zero);
+            else if (lay.n_seg <= 12) mac_rows_of_search<12>(a, sd, lay, sy, e, &masks, z_zero);
+            else if (lay.n_seg <= MAC_SMAX_SHORT) mac_rows_of_search<MAC_SMAX_SHORT>(a, sd, lay, sy, e, &masks, z_zero);
+        }
+        // (longer patterns still: mac_list_kernel, several passes)
+    }
 }
 
 // Band-split form, after survivor_kernel: forming whole rows pair by pair (mac_list_kernel, ~110 ns a pair) beats the dense
@@ -1916,6 +2012,7 @@ struct SubBatch {
     int item_first[2];                  // [mac_kernel, mac_long_kernel]: into the item array (items of 1 + MAC_SPW ints)
     int item_count[2];
     int chunk_group[2];                 // bin chunks an XCD works on at a time
+    int long_patterns;                  // searches whose pattern has more than MAC_SMAX_LONG segments
 };
 
 struct Plan {
@@ -1953,6 +2050,9 @@ int build_plan(const std::vector<SearchDesc>& s, size_t ws_bytes, Plan& plan) {
         if (b0 == a0) return SUSHI_HIP_ENOSPACE;
         SubBatch sb;
         sb.a0 = a0; sb.b0 = b0; sb.pairs = pairs; sb.segs = segs;
+        sb.long_patterns = 0;
+        for (int k = a0; k < b0; ++k)
+            if ((s[k].tmpl_len + FFT_SEG - 1) / FFT_SEG > mac_class_smax(MAC_CLASSES - 1)) ++sb.long_patterns;
         sb.first_pair = s[a0].first_pair; sb.first_seg = s[a0].first_seg;
         // every pair of the sub-batch, keyed by the region of the destination stream it scores (its absolute pair
         // index); workgroup b runs on XCD b % 8 (observed; speed only)
@@ -2423,7 +2523,9 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
                     if (hipMemcpyAsync(b->band_votes, scount + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
                         hipStreamSynchronize(st) != hipSuccess)
                         return SUSHI_HIP_ELAUNCH;
-                    b->band = b->band_votes[0] > 0 && (double)b->band_votes[1] >= 0.9 * (double)b->band_votes[0] ? 1 : 0;
+                    // (measured at BASELINE configs[2]: 97 % of the pairs vote for it at 12 dB of noise on the source -- 9.7 ms against 17.5 for
+                    // the whole-row form --, 87 % at 6 dB -- 12.5 against 17.5 --, 14 % at 0 dB -- 28.7 against 18.7)
+                    b->band = b->band_votes[0] > 0 && (double)b->band_votes[1] >= 0.75 * (double)b->band_votes[0] ? 1 : 0;
                     b->band_decided_method = b->method;
                 }
                 band = b->band;
@@ -2489,9 +2591,9 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             return launch_ok();
         };
         // the whole rows of LISTED pairs (band-split form: nothing but the low band exists until a pair is to be transformed)
-        auto launch_mac_list = [&](const int* list, const int* count, int n_list, const int* disable) {
+        auto launch_mac_list = [&](const int* list, const int* count, int n_list, const int* disable, int long_only) {
             MacListArgs la;
-            la.disable = disable;
+            la.disable = disable; la.long_only = long_only;
             la.spec = (const uint4*)dst->spec; la.spec_blocks = dst->blocks; la.tspec = (const uint4*)tspec; la.y = y;
             la.searches = searches_dev + sbt.a0; la.tconst = tconst; la.pairmap = pairmap; la.list = list; la.count = count;
             la.n_list = n_list; la.sub_first_seg = sbt.first_seg; la.sub_first_pair = sbt.first_pair;
@@ -2527,7 +2629,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             IfftArgs ip = ia;
             ip.slb = ba.slb; ip.audit_mark = nullptr;              // (the pairs transformed first are nobody's excluded pairs)
             ip.order = ba.plist; ip.count = nullptr;
-            if (band && launch_mac_list(ba.plist, nullptr, n_sub, nullptr) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+            if (band && launch_mac_list(ba.plist, nullptr, n_sub, nullptr, 0) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             if (launch_ifft(ip, (unsigned)n_sub) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             hipLaunchKernelGGL(survivor_kernel, dim3((unsigned)((sbt.pairs + 255) / 256)), dim3(256), 0, st, ba);
             if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
@@ -2538,13 +2640,23 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
                 int* dense = scount + 4;
                 hipLaunchKernelGGL(dense_mode_kernel, dim3(1), dim3(1), 0, st, (const int*)ba.scount, (int)sbt.pairs, dense);
                 if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-                if (launch_mac_list(ba.slist, ba.scount, (int)sbt.pairs, dense) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+                {
+                    MacRowsArgs ra;
+                    ra.spec = (const uint4*)dst->spec; ra.spec_blocks = dst->blocks; ra.tspec = (const uint4*)tspec; ra.y = y;
+                    ra.searches = searches_dev + sbt.a0; ra.tconst = tconst; ra.mark = ba.audit_mark; ra.n_sub = n_sub;
+                    ra.sub_first_seg = sbt.first_seg; ra.sub_first_pair = sbt.first_pair; ra.disable = dense;
+                    const int64_t want = (int64_t)n_sub * MACL_PARTS;
+                    if (sbt.item_count[0] > 0) hipLaunchKernelGGL(mac_rows_kernel<0>, dim3((unsigned)std::min<int64_t>(want, 256 * 32)), dim3(MACL_THREADS), 0, st, ra);
+                    if (sbt.item_count[1] > 0) hipLaunchKernelGGL(mac_rows_kernel<1>, dim3((unsigned)std::min<int64_t>(want, 256 * 16)), dim3(MACL_THREADS), 0, st, ra);
+                    if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+                }
+                if (sbt.long_patterns && launch_mac_list(ba.slist, ba.scount, (int)sbt.pairs, dense, 1) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
                 if (launch_mac(false, dense) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             }
-            // One workgroup per list slot up to what the list usually holds (a sixteenth of the pairs: empty slots there cost a
+            // One workgroup per list slot up to what the list usually holds (an eighth of the pairs: empty slots there cost a
             // workgroup's launch each, ~1 ns), and a fixed grid striding over whatever lies beyond: the striding form alone runs
             // at half the rate per pair (the loop costs it registers), one workgroup per POSSIBLE slot cost 0.3 ms of empty launches.
-            const unsigned direct = (unsigned)std::min<int64_t>(sbt.pairs, std::max<int64_t>(4096, sbt.pairs / 16));
+            const unsigned direct = (unsigned)std::min<int64_t>(sbt.pairs, std::max<int64_t>(4096, sbt.pairs / 8));
             ip.list_first = 0; ip.list_direct = 1;
             if (launch_ifft(ip, direct) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             if ((int64_t)direct < sbt.pairs) {
