@@ -605,17 +605,19 @@ def main():
             roofline = {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": None,
                         "traffic": None, "note": "dry run: nothing was computed"}
         elif args.path == "fft":
-            # dominant kernel of the step = the stage with the largest HIP-event time; its duration is
-            # the sum over the step's sub-batch launches of that kernel
+            # Since round 5 no single kernel dominates the step (three stages of a quarter each, none of which moves the searches'
+            # own bytes: they multiply, bound and transform spectra): the roofline figure is the WHOLE STEP's -- the algorithmic
+            # bytes of one launch of the hot path over the HIP-event time of all its kernels --, the stage with the largest
+            # HIP-event time is reported beside it with its own share and its own measured HBM traffic.
             stages = {n: float(v) for n, v in zip(_native.STAGE_NAMES, stage_ms)}
             dom = max(stages, key=stages.get)
             dom_ms = stages[dom]
             kname = _native.STAGE_KERNELS[dom]
-            achieved = batch.algorithmic_bytes / (dom_ms * 1e-3) / 1e9
-            # HBM bytes of that kernel per launch from the committed rocprofv3 PMC passes of this very workload
+            achieved = batch.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
+            # HBM bytes per step of every kernel from the committed rocprofv3 PMC passes of this very workload
             # (profiles/pmc_traffic.json, made by tools/make_pmc_traffic.py).  The entry records the digest of the
             # kernel sources it was measured on: a different digest means the kernels changed since -> null.
-            traffic, traffic_bytes, step_traffic, traffic_note = None, None, None, "no PMC entry for this workload"
+            traffic, dom_traffic_bytes, step_traffic, traffic_note = None, None, None, "no PMC entry for this workload"
             wl_key = "config%d/fft/%s/%d/w%g/m%g/n%d" % (args.config, args.sample_type, n_total, cfg["window"],
                                                         cfg["minutes"], world)
             if args.method != "sqdiff_normed":
@@ -627,6 +629,7 @@ def main():
             if args.exclusion not in (None, "auto"):
                 wl_key += "/exclusion-" + args.exclusion
             digest = kernel_source_digest()
+            per_kernel = None
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                     entry = json.load(f)[wl_key]
@@ -636,12 +639,11 @@ def main():
                     traffic_note = "stale: PMC passes were taken on kernel sources %s, this is %s" % (
                         entry.get("kernel_source_digest"), digest)
                 else:
-                    kerns = [entry["kernels"][kn] for kn in _native.STAGE_KERNEL_SETS[dom] if kn in entry["kernels"]]
-                    if not kerns:
-                        raise KeyError(kname)
-                    traffic_bytes = float(sum(kk["fetch_bytes"] + kk["write_bytes"] for kk in kerns))
-                    traffic = traffic_bytes / (dom_ms * 1e-3) / 1e9
                     step_traffic = float(sum(k["fetch_bytes"] + k["write_bytes"] for k in entry["kernels"].values()))
+                    traffic = step_traffic / (kernel_ms * 1e-3) / 1e9
+                    kerns = [entry["kernels"][kn] for kn in _native.STAGE_KERNEL_SETS[dom] if kn in entry["kernels"]]
+                    dom_traffic_bytes = float(sum(kk["fetch_bytes"] + kk["write_bytes"] for kk in kerns)) if kerns else None
+                    per_kernel = {kn: {"read": kk["fetch_bytes"], "written": kk["write_bytes"]} for kn, kk in sorted(entry["kernels"].items())}
                     traffic_note = "%s @ %s" % (entry.get("source"), entry.get("source_commit"))
                     # where a kernel's write bytes are not a WRITE_SIZE pass (tools/make_pmc_traffic.py), say what they are
                     others = sorted(set(k.get("write_source", "WRITE_SIZE") for k in entry["kernels"].values()) - {"WRITE_SIZE"})
@@ -651,21 +653,25 @@ def main():
                 pass
             roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                         "frac": achieved / PEAK_HBM_GBPS, "traffic": traffic,
-                        "traffic_bytes_per_launch": traffic_bytes,
-                        # all kernels of the step together (PMC), next to what the algorithm needs: the formulation's
-                        # own bytes (the Y round trip) are in this ratio
+                        "basis": "whole step: algorithmic bytes of one launch of the hot path / HIP-event time of all its kernels; "
+                                 "`traffic` = PMC bytes (FETCH_SIZE x 2 + WRITE_SIZE, all kernels of a step) / the same time",
+                        "kernel": "all kernels of one sushi_hip_batch_run", "kernel_ms": kernel_ms,
                         "step_traffic_bytes": step_traffic,
                         "step_traffic_over_algorithmic": None if step_traffic is None else
                         step_traffic / batch.algorithmic_bytes,
+                        "traffic_bytes_per_kernel_per_step": per_kernel,
+                        "dominant_stage": {"stage": dom, "kernels": kname, "ms": dom_ms, "share_of_step": dom_ms / kernel_ms,
+                                           "traffic_bytes_per_step": dom_traffic_bytes,
+                                           "traffic_GBps": None if dom_traffic_bytes is None else dom_traffic_bytes / (dom_ms * 1e-3) / 1e9},
                         "traffic_key": wl_key, "traffic_source": traffic_note,
                         "kernel_source_digest": digest,
                         # the binary that actually ran (the digest above is of the sources on disk)
                         "library": loaded_library(),
-                        "kernel": kname, "kernel_ms": dom_ms, "launches_per_step": batch.sub_batches,
+                        "launches_per_step": batch.sub_batches,
                         "stage_ms": stages,
                         "step_kernels_ms": kernel_ms,
-                        "step_hbm_achieved_GBps": batch.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9,
-                        "step_frac": batch.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                        "step_hbm_achieved_GBps": achieved,
+                        "step_frac": achieved / PEAK_HBM_GBPS,
                         "algorithmic_bytes_per_launch": batch.algorithmic_bytes,
                         "direct_form_flop_per_launch": flops_launch,
                         "direct_form_equivalent_TFLOPs": flops_launch / (kernel_ms * 1e-3) / 1e12,

@@ -25,12 +25,13 @@ VIEW_XC, VIEW_S1, VIEW_S2, VIEW_UREL, VIEW_BASE, VIEW_SPECTRA, VIEW_USREL, VIEW_
 ABI_VERSION = 10
 NSTAGES = 6
 STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish", "bound")
-STAGE_KERNELS = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "mac_list_kernel+ifft_kernel", "refine": "refine_kernel",
+STAGE_KERNELS = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "mac_list_kernel+mac_rows_kernel+ifft_kernel", "refine": "refine_kernel",
                  "finish": "collect_kernel+exact_tiles_kernel+unpack_keys_kernel", "bound": "bound_low_kernel|bound_kernel"}
 EXCLUSION = {"auto": 0, "always": 1, "never": 2, "band": 3, "whole": 4}        # SUSHI_HIP_EXCLUDE_*
 # every kernel a stage's HIP-event span covers (profiles/pmc_traffic.json is keyed by kernel)
 STAGE_KERNEL_SETS = {"tspec": ("tspec_kernel",), "mac": ("mac_kernel", "mac_long_kernel"),
-                     "ifft": ("ifft_kernel", "pilot_kernel", "survivor_kernel", "mac_list_kernel"), "refine": ("refine_kernel",),
+                     "ifft": ("ifft_kernel", "ifft_list_kernel", "pilot_kernel", "survivor_kernel", "mac_list_kernel", "mac_rows_kernel"),
+                     "refine": ("refine_kernel",),
                      "finish": ("collect_kernel", "exact_tiles_kernel"), "bound": ("bound_kernel", "bound_low_kernel", "slb_kernel")}
 
 # struct SushiHipRequest, 24 bytes
