@@ -212,6 +212,10 @@ SUSHI_HIP_API int sushi_hip_batch_set_method(SushiHipBatch* batch, int method);
 #define SUSHI_HIP_EXCLUDE_BAND 3
 #define SUSHI_HIP_EXCLUDE_WHOLE 4
 SUSHI_HIP_API int sushi_hip_batch_set_exclusion(SushiHipBatch* batch, int mode);
+/* Multi-GPU callers: every following run ALSO writes its results as n 8-byte records (int32 index, float32 score bits) to
+ * out_packed_dev (8-byte aligned, n records; NULL = off) -- the block a rank contributes to the one all-gather of the path, written
+ * by the kernel that writes out_idx / out_score instead of by two copies afterwards. */
+SUSHI_HIP_API int sushi_hip_batch_set_packed_output(SushiHipBatch* batch, int32_t* out_packed_dev);
 /* One pass of the hot path over the batch (asynchronous):
  *   out_idx_dev[n]   = result.argmin(axis=1)[0]        (wav.py:186)
  *   out_score_dev[n] = result[0][min_idx], float32     (wav.py:188)

@@ -2225,6 +2225,7 @@ struct SushiHipBatch {
     int suspended;                      // 1: the exclusion is left out (AUTO)
     unsigned suspended_at;              // run_seq of the run that showed it
     int last_suspended;                 // whether the last run was one of those
+    int32_t* packed_out;                // NULL, or where every run ALSO leaves its results as 8-byte (index, score bits) records
     int64_t n_tiles;
     int64_t direct_pairs;               // pairs of the last run's sub-batches that were transformed without the exclusion
     std::vector<SearchDesc> descs;
@@ -2327,6 +2328,7 @@ int sushi_hip_batch_create(const SushiHipStream* dst, const SushiHipStream* src,
     std::unique_ptr<SushiHipBatch> guard(b);                     // freed on every early return and on an exception
     b->dst = dst; b->src = src; b->n = n; b->path = path; b->variant = variant; b->method = SUSHI_HIP_METHOD_SQDIFF_NORMED;
     b->exclusion = SUSHI_HIP_EXCLUDE_AUTO;
+    b->packed_out = nullptr;
     b->host_stats = nullptr; b->stats_ready = nullptr; b->stats_pending = false; b->suspended = 0; b->suspended_at = 0; b->last_suspended = 0;
     b->band = -1; b->last_band = -1; b->band_decided_method = -1; b->band_votes[0] = b->band_votes[1] = 0; b->run_seq = 0; b->audit_every = 2;
     {
@@ -2395,6 +2397,13 @@ int sushi_hip_batch_set_method(SushiHipBatch* b, int method) {
     return SUSHI_HIP_OK;
 }
 
+int sushi_hip_batch_set_packed_output(SushiHipBatch* b, int32_t* out_packed_dev) {
+    if (!b) return SUSHI_HIP_EINVAL;
+    if ((uintptr_t)out_packed_dev & 7) return SUSHI_HIP_EALIGN;
+    b->packed_out = out_packed_dev;
+    return SUSHI_HIP_OK;
+}
+
 int sushi_hip_batch_set_exclusion(SushiHipBatch* b, int mode) {
     if (!b || mode < SUSHI_HIP_EXCLUDE_AUTO || mode > SUSHI_HIP_EXCLUDE_WHOLE) return SUSHI_HIP_EINVAL;
     b->exclusion = mode;
@@ -2418,7 +2427,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
     if (hipStreamWaitEvent(st, b->uploaded, 0) != hipSuccess) return SUSHI_HIP_ELAUNCH;   // descriptors and plan have landed
     if (b->path == SUSHI_HIP_PATH_DIRECT)
         return launch_direct(r, searches_dev, n_search, (int)b->n_tiles, b->variant, b->method, keys, out_idx_dev,
-                             out_score_dev, st);
+                             out_score_dev, b->packed_out, st);
 
     if (!(delta >= 3.8e-6) || delta > 1.0) return SUSHI_HIP_EINVAL;      // the floor covers the scoring arithmetic's own rounding
     unsigned long long* gkeys = keys + n_search;
@@ -2694,7 +2703,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         prof_end(pc, t0, SUSHI_HIP_STAGE_FINISH, st);
     }
     hipEvent_t t0 = prof_begin(pc, st);
-    const int rc = launch_unpack(keys, n_search, b->method, out_idx_dev, out_score_dev, st);
+    const int rc = launch_unpack(keys, n_search, b->method, out_idx_dev, out_score_dev, b->packed_out, st);
     prof_end(pc, t0, SUSHI_HIP_STAGE_FINISH, st);
     if (rc == SUSHI_HIP_OK && excluded_any && b->exclusion == SUSHI_HIP_EXCLUDE_AUTO && !b->stats_pending) {
         // what this run's exclusion left, for the runs after it (never waited for: the event is queried)

@@ -453,12 +453,15 @@ void exact_tiles_kernel(TileParams a) {
 }
 
 __global__ void unpack_keys_kernel(const unsigned long long* __restrict__ keys, int n, int method,
-                                   int32_t* __restrict__ out_idx, float* __restrict__ out_score) {
+                                   int32_t* __restrict__ out_idx, float* __restrict__ out_score, int2* __restrict__ out_packed) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) {
         const unsigned long long key = keys[k];
+        const float sc = method == SUSHI_HIP_METHOD_CCOEFF_NORMED ? key_score_max(key) : key_score(key);
         out_idx[k] = (int32_t)key_pos(key);
-        out_score[k] = method == SUSHI_HIP_METHOD_CCOEFF_NORMED ? key_score_max(key) : key_score(key);
+        out_score[k] = sc;
+        // the same pair once more as ONE 8-byte record (index, score bits): what a rank hands to the all-gather as it is
+        if (out_packed) out_packed[k] = int2{(int)key_pos(key), __float_as_int(sc)};
     }
 }
 
@@ -951,14 +954,14 @@ int direct_variant_tile(int variant) {
 }
 
 int launch_unpack(const unsigned long long* keys_dev, int n, int method, int32_t* out_idx_dev, float* out_score_dev,
-                  hipStream_t st) {
+                  int32_t* out_packed_dev, hipStream_t st) {
     hipLaunchKernelGGL(unpack_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, keys_dev, n, method, out_idx_dev,
-                       out_score_dev);
+                       out_score_dev, reinterpret_cast<int2*>(out_packed_dev));
     return launch_ok();
 }
 
 int launch_direct(const StreamRefs& r, const SearchDesc* searches_dev, int n_search, int n_tiles, int variant, int method,
-                  unsigned long long* keys_dev, int32_t* out_idx_dev, float* out_score_dev, hipStream_t st) {
+                  unsigned long long* keys_dev, int32_t* out_idx_dev, float* out_score_dev, int32_t* out_packed_dev, hipStream_t st) {
     if (n_tiles < n_search || variant < 0 || variant >= kNumVariants) return SUSHI_HIP_EINVAL;
     if (method != SUSHI_HIP_METHOD_SQDIFF_NORMED && method != SUSHI_HIP_METHOD_CCOEFF_NORMED) return SUSHI_HIP_EINVAL;
     if (hipMemsetAsync(keys_dev, 0xff, (size_t)n_search * sizeof(uint64_t), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
@@ -973,7 +976,7 @@ int launch_direct(const StreamRefs& r, const SearchDesc* searches_dev, int n_sea
         default: hipLaunchKernelGGL((match_sqdiff_f32_kernel<4, 4>), dim3(n_tiles), dim3(256), 0, st, a); break;
     }
     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-    return launch_unpack(keys_dev, n_search, method, out_idx_dev, out_score_dev, st);
+    return launch_unpack(keys_dev, n_search, method, out_idx_dev, out_score_dev, out_packed_dev, st);
 }
 
 int launch_refine(const RefineParams& p, hipStream_t st) {

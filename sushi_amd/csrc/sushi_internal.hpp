@@ -84,7 +84,7 @@ int direct_variant_tile(int variant);
 
 // direct path: one launch of the MFMA kernel + unpack
 int launch_direct(const StreamRefs& r, const SearchDesc* searches_dev, int n_search, int n_tiles, int variant, int method,
-                  unsigned long long* keys_dev, int32_t* out_idx_dev, float* out_score_dev, hipStream_t st);
+                  unsigned long long* keys_dev, int32_t* out_idx_dev, float* out_score_dev, int32_t* out_packed_dev, hipStream_t st);
 
 // FFT path, exact stages (sushi_hip.hip):
 // refine: exact float64 evaluation of the listed candidates of searches [first_search, first_search + n_sub).
@@ -120,7 +120,7 @@ struct TileParams {
 };
 int launch_tiles(const TileParams& p, hipStream_t st);
 int launch_unpack(const unsigned long long* keys_dev, int n, int method, int32_t* out_idx_dev, float* out_score_dev,
-                  hipStream_t st);
+                  int32_t* out_packed_dev, hipStream_t st);
 
 }  // namespace sushi
 #endif

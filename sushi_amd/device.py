@@ -252,6 +252,20 @@ class SearchBatch(object):
     def handle(self):
         return self._handle
 
+    def set_packed_output(self, packed):
+        """Multi-GPU callers: every following run() also leaves its results as (index, score bits) int32 pairs in the first n rows
+        of `packed` (a contiguous int32 CUDA tensor [>= n, 2]) -- a rank's block of the all-gather, written by the library's last
+        kernel instead of by two copies afterwards (sushi_amd.distributed.ShardedSearch).  None turns it off."""
+        if packed is None:
+            _native.check(_native.lib().sushi_hip_batch_set_packed_output(self._handle, None), "sushi_hip_batch_set_packed_output")
+            self._packed = None
+            return
+        if packed.dtype != torch.int32 or not packed.is_cuda or not packed.is_contiguous() or packed.dim() != 2 or \
+                packed.shape[1] != 2 or packed.shape[0] < self.n:
+            raise SushiError("packed output: a contiguous int32 CUDA tensor [>= n, 2]")
+        _native.check(_native.lib().sushi_hip_batch_set_packed_output(self._handle, packed.data_ptr()), "sushi_hip_batch_set_packed_output")
+        self._packed = packed           # kept alive with the batch
+
     def run(self, hip_stream=None):
         """One pass of the hot path over this batch (asynchronous)."""
         st = _raw_stream(self.dst.device) if hip_stream is None else hip_stream

@@ -106,8 +106,9 @@ class ShardedSearch(object):
     tensors only, so it must be this rank's GPU under the nccl backend (None: CPU, for gloo).
     `weights` (one positive number per search, the same on every rank): blocks of equal work instead of equal count.
 
-    The gather's buffers are allocated once: a step costs two small copies into the packed block, the one collective and
-    one (equal blocks) or two (unequal blocks) small kernels on the way out; at 375 events per rank a step is 3.5 ms of
+    The gather's buffers are allocated once; a batch that can write its (index, score bits) records itself (SearchBatch.
+    set_packed_output) does so from the second step on: a step is then the library's kernels, the one collective and one (equal
+    blocks) or two (unequal blocks) small kernels on the way out; at 375 events per rank a step is 3.5 ms of
     kernels, and a dozen tiny launches around the collective would be a few per cent of it.
 
     CONTRACT of gather() / run(): the two returned tensors are CONTIGUOUS rows of one persistent buffer of this object --
@@ -126,6 +127,7 @@ class ShardedSearch(object):
         self.lo, self.hi = self._bounds[self.rank]
         self.batch = make_batch(self.lo, self.hi) if self.hi > self.lo else None
         self._packed = self._full = self._out = self._rows = self._sel = None
+        self._self_packed = False
 
     def all_bounds(self):
         return list(self._bounds)
@@ -151,9 +153,18 @@ class ShardedSearch(object):
                 sel = np.concatenate([np.arange(hi - lo, dtype=np.int64) + r * pad for r, (lo, hi) in enumerate(self._bounds)])
                 self._sel = torch.from_numpy(sel).to(dev)
                 self._rows = torch.empty((self.n_total, 2), dtype=torch.int32, device=dev)
+            # a batch that can write its (index, score bits) records itself does, from now on: a step is then the library's
+            # kernels, the one collective and one small kernel on the way out -- no copies in between
+            if self.batch is not None and hasattr(self.batch, "set_packed_output") and idx.is_cuda:
+                self.batch.set_packed_output(self._packed)
+                self._self_packed = True
+                n = idx.shape[0]                                  # (this step's results exist already: packed by hand once)
+                self._packed[:n, 0].copy_(idx)
+                self._packed[:n, 1].copy_(score.view(torch.int32))
         n = idx.shape[0]
-        self._packed[:n, 0].copy_(idx)
-        self._packed[:n, 1].copy_(score.view(torch.int32))
+        if not self._self_packed:
+            self._packed[:n, 0].copy_(idx)
+            self._packed[:n, 1].copy_(score.view(torch.int32))
         dist.all_gather_into_tensor(self._full, self._packed, group=self.group)
         rows = self._full
         if self._sel is not None:

@@ -837,3 +837,28 @@ def test_short_pattern_with_dozens_of_near_tie_candidates(oracle, dtype, M):
     assert int(idx[0]) == best * period + a
     d = b.diagnostics()
     assert d["flagged"] == 0 and d["all_positions"] == 0
+
+
+def test_packed_output_is_the_same_results_as_8_byte_records():
+    """sushi_hip_batch_set_packed_output: what a rank hands to the all-gather -- (index, score bits) per search -- written by the
+    kernel that writes out_idx / out_score, on both paths."""
+    import torch
+    from sushi_amd.device import DeviceStream, SearchBatch
+    rng = np.random.default_rng(9)
+    dst = rng.random(60000, dtype=np.float32)
+    src = dst[1000:30000].copy()
+    for path in ("fft", "direct"):
+        b = SearchBatch(DeviceStream(dst), DeviceStream(src), [0, 5000, 9000], [3000, 700, 4097], [500, 2000, 8000], [20000, 30000, 9000],
+                        path=path)
+        packed = torch.full((5, 2), -7, dtype=torch.int32, device="cuda")
+        b.set_packed_output(packed)
+        b.run()
+        idx, score = b.results()
+        p = packed.cpu().numpy()
+        assert (p[:3, 0] == idx).all() and (p[:3, 1].view(np.float32) == score).all() and (p[3:] == -7).all()
+        assert (idx == [500, 4000, 2000]).all()
+        b.set_packed_output(None)
+        packed.fill_(-7)
+        b.run()
+        b.results()
+        assert (packed.cpu().numpy() == -7).all()
