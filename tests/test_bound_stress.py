@@ -43,3 +43,13 @@ def test_bound_holds_on_adversarial_material(oracle, kind):
         for k in range(len(offs)):
             res = oracle.match_template(dst[wst[k]:wst[k] + npos[k] + lens[k] - 1], src[offs[k]:offs[k] + lens[k]])[0]
             (_check_u8 if u8 else _check_f32)(res, idx[k], score[k])
+        # both forms of the exclusion, several runs each (every run transforms ANOTHER excluded pair of every second search and holds
+        # its lower bound to what it really scores): no bound above a real score, the same results
+        for form in ("band", "whole"):
+            bf = SearchBatch(b.dst, b.src, offs, lens, wst, npos, path="fft", exclusion=form)
+            for _ in range(4):
+                bf.run()
+                i2, s2 = bf.results()
+                df = bf.diagnostics()
+                assert df["slb_violations"] == 0 and df["all_positions"] == 0 and df["max_slb_ratio_excluded"] < 1.0, (form, df)
+                assert (i2 == idx).all() and (s2.view(np.uint32) == score.view(np.uint32)).all(), form
