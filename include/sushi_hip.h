@@ -230,8 +230,9 @@ SUSHI_HIP_API int sushi_hip_batch_run(SushiHipBatch* batch, double delta, int32_
 SUSHI_HIP_API int sushi_hip_batch_diagnostics(SushiHipBatch* batch, SushiHipBatchDiag* diag, float* ranking_err_host,
                                               int32_t* flagged_host);
 /* FFT path, after a run: the lower bound of the scores of every block pair of the LAST sub-batch (slb_host[pairs]; -inf = no
- * bound) and what it was put together from (acc_host[pairs][2]: the bound of the cross term's magnitude in the units of the
- * stored products, the largest row energy of a wave) -- for tests and tools that look at how sharp the exclusion is.  *n_pairs
+ * bound) and what it was put together from (acc_host[pairs][2], in the units of the stored products.  Whole-row form: the bound of
+ * the cross term's magnitude, the largest row energy of a wave; band-split form: the SIGNED upper bound of the low band's part of the
+ * cross term -- sqrt(2) and bin 0 in it --, the low row's energy) -- for tests and tools that look at how sharp the exclusion is.  *n_pairs
  * in: the capacity of the arrays, out: how many pairs there are.  Synchronises. */
 SUSHI_HIP_API int sushi_hip_batch_pair_bounds(SushiHipBatch* batch, float* slb_host, float* acc_host, int64_t* n_pairs);
 SUSHI_HIP_API void sushi_hip_batch_destroy(SushiHipBatch* batch);

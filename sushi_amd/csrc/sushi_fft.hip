@@ -10,15 +10,22 @@
 //
 //   spectra_kernel   once per destination stream, for every block j (hop B):
 //                    Z_j = DFT_N( x[jB .. jB+N) + i * x[jB+H .. jB+H+N) )
+//                    (+ the low band of Z_j once more and its norms outside the band: the band-split exclusion below)
 //   tspec_kernel     per search, per pattern segment s (B samples, zero padded to N):
-//                    Tt_s = conj(DFT_N(t_s)) / N
+//                    Tt_s = conj(DFT_N(t_s)) / N                                  (+ its low band and its norm outside the band)
 //   mac_kernel       per search, per frequency bin f, per pair I of the absolute pair grid (pair I starts at
 //                    block FFT_STEP * I, FFT_STEP = 2H / B):
 //                    Y_I(f) = sum_s Tt_s(f) * Z_{FFT_STEP*I+s}(f)       (a 1-D Toeplitz product along j)
+//                    -- over every pair on the LOW rows (a quarter of the bins: the band-split form of the exclusion), or on whole
+//                    rows (the whole-row form, no exclusion, the dense fall-back); mac_list_kernel / mac_rows_kernel form the
+//                    whole rows of LISTED pairs only
+//   bound_low_kernel / bound_kernel + slb_kernel, pilot_kernel, survivor_kernel
+//                    a LOWER bound of every pair's scores without scoring it; the pair with the smallest bound of every search
+//                    is transformed first, then only the pairs whose bound is not above what the search has found
 //   ifft_kernel      y_I = IDFT_N(Y_I): Re y_I[r] / Im y_I[r] (r < H) are the cross terms of positions
 //                    FFT_STEP*I*B + r and FFT_STEP*I*B + H + r.  Fused epilogue: window energies, normalised f32
 //                    score, the pair's error bound, arg-min, and the list of positions that can still be the
-//                    minimum (candidates).
+//                    minimum (candidates); the pair's lower bound held to what it really scores (the exclusion's audit).
 //   refine_kernel    (sushi_hip.hip) exact float64 re-evaluation of the candidates -> final (index, score);
 //   collect + tiles  searches with more candidates than the lists hold: the inverse transforms of their pairs
 //                    are redone with the search's final threshold, every candidate goes to a per-tile list
@@ -2238,6 +2245,7 @@ struct SushiHipBatch {
     hipEvent_t uploaded;                // recorded on the create-time stream behind the descriptor / plan uploads
     ~SushiHipBatch() {
         if (uploaded) (void)hipEventDestroy(uploaded);
+        if (stats_pending && stats_ready) (void)hipEventSynchronize(stats_ready);       // the last run's counts may still be on their way
         if (stats_ready) (void)hipEventDestroy(stats_ready);
         if (host_stats) (void)hipHostFree(host_stats);
     }
