@@ -1357,6 +1357,10 @@ struct BoundArgs {
     unsigned char* audit_mark;        // [pairs of the sub-batch] bit 0 = excluded, transformed all the same (the audit of the exclusion); bit 1 = listed
     unsigned audit_seq;               // changes from run to run: which excluded pair of a search is audited
     int audit_every;                  // one search in this many is audited per run (0: none)
+    const int* list;                  // slb_list_kernel / bound_low_exact_kernel / survivor2_kernel: the pairs the first bound left ...
+    const int* list_count;            // ... how many
+    int* list2;                       // survivor2_kernel: the pairs the second look left ...
+    int* list2_count;                 // ... how many
 };
 
 // Stage 1 of the band-split form.  A wave takes a PAIR: the eight groups of its low row one after the other (2 KB each, the next
@@ -1514,12 +1518,8 @@ void bound_kernel(BoundArgs a) {
 // Eout = the energy over the G-aligned span around every such window; what a window holds beyond the inner span is at most 2 G
 // samples of at most Eout - Ein energy (Cauchy-Schwarz).  A flat window anywhere in the pair makes d2lb <= 0: nothing excluded.
 template <int METHOD>
-__global__ __launch_bounds__(256)
-void slb_kernel(BoundArgs a) {
+__device__ __forceinline__ void slb_one(const BoundArgs& a, const int pr, const int lane) {
     constexpr bool CC = METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED;
-    const int lane = threadIdx.x & 63;
-    const int pr = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (pr >= a.n_pairs) return;
     const int k = __builtin_amdgcn_readfirstlane(a.pairmap[pr]);
     const SearchDesc sd = a.searches[k];
     const FftLayout lay = fft_layout(sd.win_start, sd.n_pos, sd.tmpl_len);
@@ -1659,6 +1659,23 @@ void slb_kernel(BoundArgs a) {
             if (room) atomicAdd(a.band_votes + 1, 1);
         }
     }
+}
+template <int METHOD>
+__global__ __launch_bounds__(256)
+void slb_kernel(BoundArgs a) {
+    const int pr = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (pr >= a.n_pairs) return;
+    slb_one<METHOD>(a, pr, threadIdx.x & 63);
+}
+// the same for the pairs of a list (the second look at what the first bound left: bound_low_exact_kernel)
+template <int METHOD>
+__global__ __launch_bounds__(256)
+void slb_list_kernel(BoundArgs a) {
+    const int n = *a.list_count;
+    if (n > a.n_pairs / 5) return;                      // (nothing was excluded to speak of: no second look either)
+    const int waves = gridDim.x * 4;
+    for (int slot = blockIdx.x * 4 + (threadIdx.x >> 6); slot < n; slot += waves)
+        slb_one<METHOD>(a, __builtin_amdgcn_readfirstlane(a.list[slot]), threadIdx.x & 63);
 }
 
 // per search: the pair with the smallest lower bound (the first of them) is transformed first
@@ -1819,6 +1836,97 @@ void mac_rows_kernel(MacRowsArgs a) {
     }
 }
 
+// A SECOND LOOK at the pairs the band-split bound left (a few per cent of all; most of them belong to the shortest patterns, whose
+// match stands least above what chance correlates: profiles/r05/dev/survivor_stats_*.txt).  bound_low_kernel bounds the low band's
+// samples by a Cauchy-Schwarz sum over its eight decimated groups; here the N/2 samples themselves are formed -- one 8192-point
+// float32 transform of the low row (fft_core.hpp Plan<13>), bin 0 out and signed as there -- and their largest modulus taken: the
+// sharpest the sampling bound gets.  slb_list_kernel then redoes the pair's lower bound and survivor2_kernel drops what it now
+// excludes, before any whole row is formed.  ~25 ns a listed pair against ~130 for its whole row and transform.
+constexpr int BLE_LOGN = 13;
+constexpr int BLE_N = sushi_fft::Plan<BLE_LOGN>::N, BLE_T = sushi_fft::Plan<BLE_LOGN>::NT;
+static_assert(BLE_N == FN / 2, "the low band sampled at every second position");
+__global__ __launch_bounds__(BLE_T)
+void bound_low_exact_kernel(BoundArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[sushi_fft::lds_floats<BLE_LOGN>()];
+    __shared__ unsigned red[BLE_T / 64];
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const int n = *a.list_count;
+    if (n > a.n_pairs / 5) return;
+    for (int slot = blockIdx.x; slot < n; slot += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));                            // (per-iteration constants stay inside the iteration)
+        const sushi_fft::Twiddles tw = sushi_fft::load_twiddles<BLE_LOGN, 1>(tid, twiddles());
+        const int pr = a.list[slot];
+        const uint32_t* __restrict__ row = reinterpret_cast<const uint32_t*>(a.y) + (size_t)pr * (LROWE * 4);
+        cpx v[sushi_fft::PER];
+        float dc_re = 0.f, dc_im = 0.f;
+#pragma unroll
+        for (int r = 0; r < sushi_fft::PER; ++r) {
+            const int kin = sushi_fft::in_index<BLE_LOGN>(tid, r);        // index on the N/2 grid: the band is kin < N/8 and kin >= 3N/8
+            const bool in_band = kin < FN / 8 || kin >= 3 * FN / 8;
+            const int ls = sushi_fft::lslot_of_bin(kin < FN / 8 ? kin : (in_band ? kin + FN / 2 : 0));
+            const h2 h = __builtin_bit_cast(h2, in_band ? row[ls] : 0u);
+            v[r] = cpx{(float)h.x, (float)h.y};
+            if (kin == 0) { dc_re = v[r].x; dc_im = v[r].y; v[r] = cpx{0.f, 0.f}; }
+        }
+        sushi_fft::fft_split<BLE_LOGN, 1>(v, tid, lds, tw);
+        float m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < sushi_fft::PER; ++r) m2 = fmaxf(m2, v[r].x * v[r].x + v[r].y * v[r].y);
+        const unsigned wm = wave_max_u32(__float_as_uint(m2));
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = wm;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned mm = 0u;
+#pragma unroll
+            for (int i = 0; i < BLE_T / 64; ++i) mm = red[i] > mm ? red[i] : mm;
+            // sqrt(2) x the largest sample (+ the float32 transform's own error: 1e-5 of the inputs' sum of moduli, itself at most
+            // sqrt(bins x energy), acc[1]) + bin 0's own part, signed
+            const float q = a.acc[2 * (size_t)pr + 1];
+            float bw = 1.4142137f * (sqrtf(__uint_as_float(mm)) * 1.00001f + 1e-5f * sqrtf(4096.0f * q)) + fmaxf(dc_re, dc_im);
+            if (mm >= 0x7f800000u) bw = __builtin_inff();
+            // (never above the first look's: both are bounds)
+            a.acc[2 * (size_t)pr] = fminf(a.acc[2 * (size_t)pr], bw);
+        }
+        __syncthreads();
+    }
+}
+// ... and what the second look leaves: the list again, without the pairs whose new bound excludes them
+__global__ __launch_bounds__(256)
+void survivor2_kernel(BoundArgs a) {
+    const int n = *a.list_count;
+    const bool second_look = n <= a.n_pairs / 5;
+    for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
+        const int slot = base + threadIdx.x;
+        bool keep = false;
+        int pr = 0;
+        if (slot < n) {
+            pr = a.list[slot];
+            keep = true;
+            if (second_look && !(a.audit_mark[pr] & 1)) {
+                const int k = a.pairmap[pr];
+                const unsigned long long g = a.gkeys[a.first_search + k];
+                const float U = g == NO_KEY ? __builtin_inff() : key_score(g);
+                if (U < 0.9999f && a.slb[pr] > U * 1.000001f + 1e-7f) {
+                    keep = false;
+                    a.pair_lb[pr] = __builtin_inff();
+                    a.audit_mark[pr] = 0;
+                }
+            }
+        }
+        const unsigned long long m = __ballot(keep), act = __ballot(slot < n);
+        const int lane = threadIdx.x & 63;
+        const int dropped = __popcll(act) - __popcll(m);
+        int b0 = 0;
+        if (lane == 0 && m) b0 = atomicAdd(a.list2_count, __popcll(m));
+        if (lane == 0 && dropped > 0)                          // (they were counted as transformed when they were listed)
+            atomicAdd(&a.counters->pairs_transformed, (unsigned long long)0 - (unsigned long long)dropped);
+        b0 = __shfl(b0, 0, 64);
+        if (keep) a.list2[b0 + __popcll(m & ((1ull << lane) - 1ull))] = pr;
+    }
+}
+
 // Band-split form, after survivor_kernel: forming whole rows pair by pair (mac_list_kernel, ~110 ns a pair) beats the dense
 // multiply-accumulate over ALL pairs only while few are listed -- a batch whose searches find no match excludes nothing.  dense[0]
 // = 1 hands the rows to mac_kernel's whole-row form instead (both launches are queued; the one not needed leaves at once).
@@ -1961,7 +2069,7 @@ inline int64_t cand_capacity(int64_t pairs) {
 
 // bytes of workspace for one sub-batch of `pairs` block pairs, `segs` pattern segments and `searches` searches
 struct WsLayout { size_t tspec, y, cand, pair_lb, pairmap, tconst, tiles, candbuf, dummy, slb, acc, plist, slist, scount, citems,
-                  tspec_low, ylow, tnorm_rest, audit_mark, total; };
+                  tspec_low, ylow, tnorm_rest, audit_mark, slist2, total; };
 inline WsLayout ws_layout(int64_t pairs, int64_t segs, int64_t searches) {
     WsLayout w;
     size_t o = 0;
@@ -1978,13 +2086,14 @@ inline WsLayout ws_layout(int64_t pairs, int64_t segs, int64_t searches) {
     w.acc = o; o += align_up((size_t)pairs * 2 * sizeof(float), 256);
     w.plist = o; o += align_up((size_t)searches * sizeof(int), 256);
     w.slist = o; o += align_up((size_t)pairs * sizeof(int), 256);
-    w.scount = o; o += 256;                                                      // [0] survivors, [1] collect items, [2..3] band prediction votes, [4] dense whole rows
+    w.scount = o; o += 256;                                                      // [0] survivors, [1] collect items, [2..3] band prediction votes, [4] dense whole rows, [5] pairs left after the second look
     w.citems = o; o += align_up((size_t)pairs * sizeof(int), 256);
     // band-split exclusion: low-band rows of the pattern spectra and of the products, the pattern rows' norms outside the band
     w.tspec_low = o; o += align_up((size_t)segs * LROW_BYTES, 256);
     w.ylow = o; o += align_up((size_t)pairs * LROW_BYTES, 256);
     w.tnorm_rest = o; o += align_up((size_t)segs * sizeof(float), 256);
     w.audit_mark = o; o += align_up((size_t)pairs, 256);
+    w.slist2 = o; o += align_up((size_t)pairs * sizeof(int), 256);
     w.total = o;
     return w;
 }
@@ -2650,12 +2759,25 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             if (launch_ifft(ip, (unsigned)n_sub) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             hipLaunchKernelGGL(survivor_kernel, dim3((unsigned)((sbt.pairs + 255) / 256)), dim3(256), 0, st, ba);
             if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-            ip.order = ba.slist; ip.count = ba.scount; ip.audit_mark = ba.audit_mark;
+            const int* final_list = ba.slist;
+            const int* final_count = ba.scount;
             if (band) {
+                // the second look at what the bound left (header of bound_low_exact_kernel): sharper bound, shorter list
+                ba.list = ba.slist; ba.list_count = ba.scount;
+                ba.list2 = (int*)(wsp + wl.slist2); ba.list2_count = scount + 5;
+                if (hipMemsetAsync(scount + 5, 0, sizeof(int), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+                hipLaunchKernelGGL(bound_low_exact_kernel, dim3(256 * 4), dim3(BLE_T), 0, st, ba);
+                if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+                if (ccm) hipLaunchKernelGGL(slb_list_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3(256 * 2), dim3(256), 0, st, ba);
+                else hipLaunchKernelGGL(slb_list_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3(256 * 2), dim3(256), 0, st, ba);
+                if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+                hipLaunchKernelGGL(survivor2_kernel, dim3(256), dim3(256), 0, st, ba);
+                if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+                final_list = ba.list2; final_count = ba.list2_count;
                 // whole rows of what is left: pair by pair while few are (the usual case), by the dense multiply-accumulate over all
                 // pairs when the bound excluded little (searches without a match: nothing can be excluded) -- decided on the device
                 int* dense = scount + 4;
-                hipLaunchKernelGGL(dense_mode_kernel, dim3(1), dim3(1), 0, st, (const int*)ba.scount, (int)sbt.pairs, dense);
+                hipLaunchKernelGGL(dense_mode_kernel, dim3(1), dim3(1), 0, st, final_count, (int)sbt.pairs, dense);
                 if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
                 {
                     MacRowsArgs ra;
@@ -2667,9 +2789,10 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
                     if (sbt.item_count[1] > 0) hipLaunchKernelGGL(mac_rows_kernel<1>, dim3((unsigned)std::min<int64_t>(want, 256 * 16)), dim3(MACL_THREADS), 0, st, ra);
                     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
                 }
-                if (sbt.long_patterns && launch_mac_list(ba.slist, ba.scount, (int)sbt.pairs, dense, 1) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+                if (sbt.long_patterns && launch_mac_list(final_list, final_count, (int)sbt.pairs, dense, 1) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
                 if (launch_mac(false, dense) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             }
+            ip.order = final_list; ip.count = final_count; ip.audit_mark = ba.audit_mark;
             // One workgroup per list slot up to what the list usually holds (an eighth of the pairs: empty slots there cost a
             // workgroup's launch each, ~1 ns), and a fixed grid striding over whatever lies beyond: the striding form alone runs
             // at half the rate per pair (the loop costs it registers), one workgroup per POSSIBLE slot cost 0.3 ms of empty launches.
