@@ -30,7 +30,8 @@ STAGE_KERNELS = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "mac_list
 EXCLUSION = {"auto": 0, "always": 1, "never": 2, "band": 3, "whole": 4}        # SUSHI_HIP_EXCLUDE_*
 # every kernel a stage's HIP-event span covers (profiles/pmc_traffic.json is keyed by kernel)
 STAGE_KERNEL_SETS = {"tspec": ("tspec_kernel",), "mac": ("mac_kernel", "mac_long_kernel"),
-                     "ifft": ("ifft_kernel", "ifft_list_kernel", "pilot_kernel", "survivor_kernel", "mac_list_kernel", "mac_rows_kernel"),
+                     "ifft": ("ifft_kernel", "ifft_list_kernel", "pilot_kernel", "survivor_kernel", "mac_list_kernel", "mac_rows_kernel",
+                              "bound_low_exact_kernel", "slb_list_kernel", "survivor2_kernel"),
                      "refine": ("refine_kernel",),
                      "finish": ("collect_kernel", "exact_tiles_kernel"), "bound": ("bound_kernel", "bound_low_kernel", "slb_kernel")}
 

@@ -41,7 +41,8 @@ res = {}
 # left), with very different sizes; without it the average dispatch stands for the step (round 4's entries)
 runs = int(os.environ.get("PMC_RUNS", "0"))
 for k, fetch_scale in (('ifft_kernel', 2.0), ('ifft_list_kernel', 2.0), ('mac_kernel', 2.0), ('mac_long_kernel', 2.0), ('bound_kernel', 2.0),
-                       ('bound_low_kernel', 2.0), ('mac_list_kernel', 2.0), ('mac_rows_kernel', 2.0), ('tspec_kernel', 1.0),
+                       ('bound_low_kernel', 2.0), ('bound_low_exact_kernel', 1.0), ('mac_list_kernel', 2.0), ('mac_rows_kernel', 2.0), ('tspec_kernel', 1.0),
+                       ('slb_list_kernel', 1.0), ('survivor2_kernel', 1.0),
                        ('refine_kernel', 1.0), ('collect_kernel', 2.0), ('exact_tiles_kernel', 1.0), ('slb_kernel', 1.0),
                        ('pilot_kernel', 1.0), ('survivor_kernel', 1.0)):
     if k not in rows or rows[k].get('FETCH_SIZE') is None:
