@@ -1935,7 +1935,7 @@ __global__ void dense_mode_kernel(const int* scount, int n_pairs, int* dense) { 
 // Collection pass over the flagged searches of a sub-batch: the same transforms and scores again (bit for bit), now
 // against the search's final threshold; every candidate goes to its tile's list, tiles with many candidates (or
 // when the buffer is full) are marked dense.  A fixed grid strides over the (search, pair) items refine_kernel listed.
-constexpr int SPARSE_MAX = 256;            // candidates per tile up to which they are listed; beyond: every position
+constexpr int SPARSE_MAX = SPARSE_TILE_MAX; // candidates per tile up to which they are listed; beyond: every position
 constexpr int COLLECT_GRID = 1024;         // collect_kernel's workgroups: two per CU, twice over
 
 template <int METHOD>

@@ -308,19 +308,43 @@ __device__ __forceinline__ void chunk_run(const T* __restrict__ t, const T* __re
 // Exact evaluation of the tiles collect_kernel listed: every valid position of a dense tile (a thread owns four
 // CONSECUTIVE positions: the pattern samples T[m .. m+3] then meet the seven search samples I[p .. p+6], of which
 // four are the previous step's -- one 16-byte LDS read of each per 16 float64 FMAs), or the listed candidate
-// positions of a sparse tile (one per thread).  Fixed grid, workgroups stride over the tile list; with no tile
-// listed every workgroup leaves after one load.
+// positions of a sparse tile.  XG chunks of the pattern are staged at a time.  Fixed grid, workgroups stride over the
+// tile list; with no tile listed every workgroup leaves after one load.
+//
+// Runs of EQUAL samples (digital silence: wav.py:148-151 maps it to one mid-level value, and a pattern cut from such a span
+// ties over the whole run -- dense tiles inside or at an end of such a run are most of what a tie-saturated job lists).  Where
+// every sample the tile's positions read in a chunk is the same value v, every position's sum over that chunk is the same
+// chain of multiply-adds fma(T[m], v, .): it is formed ONCE per chunk (a thread takes a chunk) and added to every position's
+// total where the loop would have added the position's own -- the same operations in the same order, so the same bits.
+// A tile inside a run costs its chunk chains; a tile at an end of one, the two or three chunks that reach outside it.
+//
+// A sparse tile's candidates each walk a chain of M dependent multiply-adds: with one thread per candidate a tile of 30
+// candidates (a held tone: one every period) kept one wave busy for 50 chunks, 0.3 ms, and a tie-saturated job lists two
+// thousand of them.  Thread <-> (staged chunk, candidate): the chunk sums go through the LDS and are added in chunk order.
+constexpr int XG = 4;            // chunks staged together
+constexpr int XMP = XM + 2;      // a staged chunk of the pattern + padding: lanes on different chunks read different banks
+// A sparse tile's lanes read the staged window at their candidates' offsets: candidates a fixed distance apart (a held tone's
+// period: 30 samples = 240 bytes) landed on 8 of the 32 banks -- 8-way conflicts on every read, 0.6 ms a tile.  One padding
+// element per 32 spreads any such stride over the banks.
+__device__ __forceinline__ int skew(const int e) { return e + (e >> 5); }
+constexpr int XRUN = 256;        // patterns of up to XRUN chunks (131,072 samples) are looked at for runs of equal samples
 template <typename T>
 __global__ __launch_bounds__(256)
 void exact_tiles_kernel(TileParams a) {
     constexpr int XQ = XT / 256;
     // chunks are staged as float64: the conversions (quarter rate) happen once per staged sample, not once per multiply-add
-    __shared__ __attribute__((aligned(16))) double lt[XM];
-    __shared__ __attribute__((aligned(16))) double li[XT + XM];
+    __shared__ __attribute__((aligned(16))) double lt[XG * XMP];
+    __shared__ __attribute__((aligned(16))) double li[XT + XG * XM + (XT + XG * XM) / 32 + 1];
+    __shared__ double part[XG * SPARSE_TILE_MAX];     // dense: the runs' chunk chains ([n_chunks]); sparse: the staged chunks' sums per candidate
+    __shared__ double ctot[SPARSE_TILE_MAX];          // sparse: the candidates' totals
+    __shared__ int cpos[SPARSE_TILE_MAX];             // sparse: the candidates' positions, relative to the tile
     __shared__ unsigned long long red[4];
+    __shared__ int run_edge[2];
+    static_assert(XRUN <= XG * SPARSE_TILE_MAX, "the chains share the chunk sums' space");
     const int n_tiles = a.counters->n_tiles;
     if (n_tiles == 0) return;
     const int tid = threadIdx.x;
+    typedef double d2 __attribute__((ext_vector_type(2)));
     // A few tiles only (a couple of flagged searches) are a latency problem, not a throughput one: a dense tile is then cut
     // into XQ workgroups of one position per thread -- the chain of dependent multiply-adds a thread walks is a quarter as long.
     // Each position's sum is the same chain either way.
@@ -330,17 +354,18 @@ void exact_tiles_kernel(TileParams a) {
         const TileDesc td = a.tiles[v];
         const SearchDesc sd = a.searches[td.search];
         const int M = sd.tmpl_len;
+        const int n_chunks = (M + XM - 1) / XM;
         const bool dense = td.cnt < 0;
         if (!dense && sub > 0) continue;                                // a sparse tile is one workgroup's work (uniform)
         const bool quarter = dense && split > 1;
         const int p0 = td.p0 + (quarter ? sub * 256 : 0);               // may be negative: tiles sit on the absolute grid
         const int span = quarter ? 256 : XT;                            // positions this workgroup covers
+        const int cnt = dense ? 0 : min(td.cnt, SPARSE_TILE_MAX);
         const T* __restrict__ Tp = (const T*)a.r.src_raw + sd.tmpl_off;
         const T* __restrict__ Ip = (const T*)a.r.dst_raw + (sd.win_start + p0);
         const int64_t room = a.r.dst_len - (sd.win_start + p0);         // samples of the stream from Ip on
-        int mine = -1;                                                  // sparse: this thread's candidate, relative to p0
-        if (!dense && tid < td.cnt) mine = a.cand[td.off + tid] - p0;
-        double tot[XQ] = {0.0, 0.0, 0.0, 0.0};
+        __syncthreads();                                                // the previous tile's shared state is consumed
+        if (tid < cnt) { cpos[tid] = a.cand[td.off + tid] - p0; ctot[tid] = 0.0; }
         const TemplStats ts = templ_stats(a.r.src_s1, a.r.src_s2, sd.tmpl_off, M, a.r.centre);
         const double* __restrict__ w1 = a.r.dst_s1 + sd.win_start;
         const double* __restrict__ w2 = a.r.dst_s2 + sd.win_start;
@@ -360,66 +385,151 @@ void exact_tiles_kernel(TileParams a) {
                     const int p = p0 + XQ * tid + q;
                     need |= p >= 0 && p < sd.n_pos && !ccoeff_ignores_corr(w1[p + M] - w1[p], w2[p + M] - w2[p], ts, M);
                 }
-            } else if (mine >= 0) {
-                const int p = p0 + mine;
+            } else if (tid < cnt) {
+                const int p = a.cand[td.off + tid];
                 need = !ccoeff_ignores_corr(w1[p + M] - w1[p], w2[p + M] - w2[p], ts, M);
             }
             needs_corr = __syncthreads_or(need) != 0;
         }
-        for (int m0 = 0; needs_corr && m0 < M; m0 += XM) {
-            const int mc = min(XM, M - m0);
-            __syncthreads();                                            // previous chunk's (or tile's) reads are done
-            for (int e = tid; e < XM; e += 256) lt[e] = e < mc ? (double)Tp[m0 + e] : 0.0;      // zero padded: whole steps of 4
-            for (int e = tid; e < span + XM; e += 256) li[e] = (int64_t)m0 + e < room ? (double)Ip[m0 + e] : 0.0;
+        // the runs of equal samples at the tile's first and last sample: chunks [0, na) see nothing but the first one's value,
+        // chunks [nb, n_chunks) nothing but the last one's
+        int na = 0, nb = n_chunks;
+        if (dense && needs_corr && (int64_t)span + M - 1 <= room && n_chunks <= XRUN) {
+            typedef typename WideLoad<T>::V V;
+            constexpr int N = WideLoad<T>::N;
+            const int need = span + M - 1;                              // samples the tile's positions read
+            const T v0 = Ip[0], v1 = Ip[need - 1];
+            int e1 = need, e2 = -1;                                     // first sample that differs from v0 / last that differs from v1
+            int e = tid * N;
+#pragma unroll 4
+            for (; e + N <= need; e += 256 * N) {
+                const V x = *reinterpret_cast<const V*>(Ip + e);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    if (!(x.v[j] == v0)) e1 = min(e1, e + j);
+                    if (!(x.v[j] == v1)) e2 = max(e2, e + j);
+                }
+            }
+            for (; e < need; ++e) {                                     // (one thread's tail of fewer than N samples)
+                if (!(Ip[e] == v0)) e1 = min(e1, e);
+                if (!(Ip[e] == v1)) e2 = max(e2, e);
+            }
+            if (tid == 0) { run_edge[0] = need; run_edge[1] = -1; }
             __syncthreads();
-            typedef double d2 __attribute__((ext_vector_type(2)));
-            if (quarter) {
-                const d2* __restrict__ lt2 = reinterpret_cast<const d2*>(lt);
-                const double* __restrict__ wv = li + tid;
-                double acc = 0.0;
-                for (int k = 0; k < (mc + 3) / 4; ++k) {
-                    const d2 ta = lt2[2 * k], tb = lt2[2 * k + 1];
-                    const double w0 = wv[4 * k], w1 = wv[4 * k + 1], w2 = wv[4 * k + 2], w3 = wv[4 * k + 3];
-                    acc = __builtin_fma(ta.x, w0, acc);                    // pattern samples in order (padding adds exact zeros)
-                    acc = __builtin_fma(ta.y, w1, acc);
-                    acc = __builtin_fma(tb.x, w2, acc);
-                    acc = __builtin_fma(tb.y, w3, acc);
-                }
-                tot[0] += acc;
-            } else if (dense) {
-                const d2* __restrict__ li2 = reinterpret_cast<const d2*>(li) + 2 * tid;       // li[4 tid + 4 k ..]
-                const d2* __restrict__ lt2 = reinterpret_cast<const d2*>(lt);
-                double acc[XQ] = {0.0, 0.0, 0.0, 0.0};
-                d2 lo0 = li2[0], lo1 = li2[1];
-                for (int k = 0; k < (mc + 3) / 4; ++k) {
-                    const d2 hi0 = li2[2 * k + 2], hi1 = li2[2 * k + 3];
-                    const d2 ta = lt2[2 * k], tb = lt2[2 * k + 1];
-                    const double w[8] = {lo0.x, lo0.y, lo1.x, lo1.y, hi0.x, hi0.y, hi1.x, hi1.y};
-                    const double t[4] = {ta.x, ta.y, tb.x, tb.y};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {                          // pattern samples in order (padding adds exact zeros)
-#pragma unroll
-                        for (int q = 0; q < XQ; ++q) acc[q] = __builtin_fma(t[j], w[q + j], acc[q]);
-                    }
-                    lo0 = hi0; lo1 = hi1;
-                }
-#pragma unroll
-                for (int q = 0; q < XQ; ++q) tot[q] += acc[q];
-            } else if (mine >= 0) {
-                // (eight LDS reads of each operand in flight per step: one read, one multiply-add at a time, a listed candidate
-                // took as long as a whole dense tile -- three sparse tiles were the 2.6 ms of a run with two flagged searches)
-                const double* __restrict__ wv = li + mine;
+            if (e1 < need) atomicMin(&run_edge[0], e1);
+            if (e2 >= 0) atomicMax(&run_edge[1], e2);
+            __syncthreads();
+            e1 = run_edge[0]; e2 = run_edge[1];
+            // chunk c covers pattern samples [c XM, c XM + mc): the tile's positions read window samples [c XM, c XM + mc + span - 1) for it
+            if (e1 >= need) na = n_chunks;
+            else na = max(min((e1 - (span - 1)) / XM, n_chunks - 1), 0);      // (whole chunks only: the last one may be short, and is then not the run's)
+            nb = na >= n_chunks ? n_chunks : max(e2 / XM + 1, na);      // c XM > e2
+            for (int c = tid; c < n_chunks; c += 256) {
+                if (c >= na && c < nb) continue;
+                const double vd = c < na ? (double)v0 : (double)v1;
+                const T* __restrict__ tc = Tp + (size_t)c * XM;
+                const int mc = min(XM, M - c * XM);
                 double acc = 0.0;
                 int m = 0;
-                for (; m + 8 <= mc; m += 8) {
-                    double tv[8], wq[8];
+#pragma unroll 8
+                for (; m + N <= mc; m += N) {                           // (a thread walks its own chunk: loads well ahead of the chain)
+                    const V x = *reinterpret_cast<const V*>(tc + m);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { tv[j] = lt[m + j]; wq[j] = wv[m + j]; }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc = __builtin_fma(tv[j], wq[j], acc);
+                    for (int j = 0; j < N; ++j) acc = __builtin_fma((double)x.v[j], vd, acc);
                 }
-                for (; m < mc; ++m) acc = __builtin_fma(lt[m], wv[m], acc);
-                tot[0] += acc;
+                for (; m < mc; ++m) acc = __builtin_fma((double)tc[m], vd, acc);
+                part[c] = acc;
+            }
+        }
+        double tot[XQ] = {0.0, 0.0, 0.0, 0.0};
+        for (int c0 = 0; needs_corr && c0 < n_chunks; c0 += XG) {
+            const int gc = min(XG, n_chunks - c0);
+            const int m0 = c0 * XM;
+            const int gm = min(gc * XM, M - m0);                        // pattern samples of this group
+            __syncthreads();                                            // previous group's reads are done (and part[] of the runs is written)
+            const bool runs_only = c0 + gc <= na || c0 >= nb;           // (uniform)
+            if (!runs_only) {
+#pragma unroll 4
+                for (int e = tid; e < gc * XM; e += 256) lt[(e / XM) * XMP + e % XM] = e < gm ? (double)Tp[m0 + e] : 0.0;     // zero padded: whole steps of 4
+                if (dense) {
+#pragma unroll 4
+                    for (int e = tid; e < span + gc * XM; e += 256) li[e] = (int64_t)m0 + e < room ? (double)Ip[m0 + e] : 0.0;
+                } else {
+#pragma unroll 4
+                    for (int e = tid; e < span + gc * XM; e += 256) li[skew(e)] = (int64_t)m0 + e < room ? (double)Ip[m0 + e] : 0.0;
+                }
+                __syncthreads();
+            }
+            if (dense) {
+                for (int ch = 0; ch < gc; ++ch) {
+                    const int c = c0 + ch;
+                    if (c < na || c >= nb) {                            // the run's chain for this chunk: every position's chunk sum
+                        const double r = part[c];
+#pragma unroll
+                        for (int q = 0; q < XQ; ++q) tot[q] += r;
+                        continue;
+                    }
+                    const int mc = min(XM, M - c * XM);
+                    const d2* __restrict__ lt2 = reinterpret_cast<const d2*>(lt + ch * XMP);
+                    if (quarter) {
+                        const double* __restrict__ wv = li + ch * XM + tid;
+                        double acc = 0.0;
+                        for (int k = 0; k < (mc + 3) / 4; ++k) {
+                            const d2 ta = lt2[2 * k], tb = lt2[2 * k + 1];
+                            const double x0 = wv[4 * k], x1 = wv[4 * k + 1], x2 = wv[4 * k + 2], x3 = wv[4 * k + 3];
+                            acc = __builtin_fma(ta.x, x0, acc);                // pattern samples in order (padding adds exact zeros)
+                            acc = __builtin_fma(ta.y, x1, acc);
+                            acc = __builtin_fma(tb.x, x2, acc);
+                            acc = __builtin_fma(tb.y, x3, acc);
+                        }
+                        tot[0] += acc;
+                    } else {
+                        const d2* __restrict__ li2 = reinterpret_cast<const d2*>(li + ch * XM) + 2 * tid;   // li[4 tid + 4 k ..]
+                        double acc[XQ] = {0.0, 0.0, 0.0, 0.0};
+                        d2 lo0 = li2[0], lo1 = li2[1];
+                        for (int k = 0; k < (mc + 3) / 4; ++k) {
+                            const d2 hi0 = li2[2 * k + 2], hi1 = li2[2 * k + 3];
+                            const d2 ta = lt2[2 * k], tb = lt2[2 * k + 1];
+                            const double w[8] = {lo0.x, lo0.y, lo1.x, lo1.y, hi0.x, hi0.y, hi1.x, hi1.y};
+                            const double t[4] = {ta.x, ta.y, tb.x, tb.y};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {                      // pattern samples in order (padding adds exact zeros)
+#pragma unroll
+                                for (int q = 0; q < XQ; ++q) acc[q] = __builtin_fma(t[j], w[q + j], acc[q]);
+                            }
+                            lo0 = hi0; lo1 = hi1;
+                        }
+#pragma unroll
+                        for (int q = 0; q < XQ; ++q) tot[q] += acc[q];
+                    }
+                }
+            } else {
+                // thread <-> (staged chunk, candidate), chunk-major: the lanes of a wave read the same pattern sample
+                // (eight LDS reads of each operand in flight per step: one read, one multiply-add at a time, a listed candidate
+                // took as long as a whole dense tile)
+                for (int i = tid; i < gc * cnt; i += 256) {
+                    const int ch = i / cnt, j = i - ch * cnt;
+                    const int mc = min(XM, M - (c0 + ch) * XM);
+                    const double* __restrict__ tv_ = lt + ch * XMP;
+                    const int wb = ch * XM + cpos[j];                  // (the candidate's window in the skewed staging)
+                    double acc = 0.0;
+                    int m = 0;
+                    for (; m + 8 <= mc; m += 8) {
+                        double tv[8], wq[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { tv[u] = tv_[m + u]; wq[u] = li[skew(wb + m + u)]; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc = __builtin_fma(tv[u], wq[u], acc);
+                    }
+                    for (; m < mc; ++m) acc = __builtin_fma(tv_[m], li[skew(wb + m)], acc);
+                    part[i] = acc;
+                }
+                __syncthreads();
+                if (tid < cnt) {
+                    double t = ctot[tid];
+                    for (int ch = 0; ch < gc; ++ch) t += part[ch * cnt + tid];      // chunk sums in order
+                    ctot[tid] = t;
+                }
             }
         }
         auto key_at = [&](const double corr_u, const int p) {
@@ -439,8 +549,8 @@ void exact_tiles_kernel(TileParams a) {
                     best = key < best ? key : best;
                 }
             }
-        } else if (mine >= 0) {
-            best = key_at(tot[0], p0 + mine);
+        } else if (tid < cnt) {
+            best = key_at(ctot[tid], p0 + cpos[tid]);
         }
         best = wave_min_u64(best);
         if ((tid & 63) == 0) red[tid >> 6] = best;

@@ -56,6 +56,7 @@ struct StreamRefs {
 };
 
 // One exact-evaluation work item: TILE consecutive positions of one search, aligned to the absolute grid.
+constexpr int SPARSE_TILE_MAX = 256;   // candidates per tile up to which collect_kernel lists them; beyond: every position of the tile
 struct TileDesc {
     int32_t search;       // global search index
     int32_t p0;           // first position of the tile relative to the search's window (may be < 0 for the first tile)

@@ -37,6 +37,30 @@ def main():
         t0 = time.perf_counter()
         dst.find_substreams(pats, [s for s, _ in spans], [10] * len(spans))
         t_batch = time.perf_counter() - t0
+        # the triple of sushi.py:450-452 (whole / left half / right half of a group) the way calculate_shifts issues it here:
+        # one launch of three searches -- against the same three as consecutive calls, and against one call
+        import numpy as np
+        trip = {}
+        for w in (10, 30):
+            halves = [np.split(p, [p.shape[1] // 2], axis=1) for p in pats[:50]]
+            t0 = time.perf_counter()
+            got = []
+            for (s, e), p, (l, r) in zip(spans[:50], pats[:50], halves):
+                ro = l.shape[1] / 12000.0
+                got.append(dst.find_substreams([p, l, r], [s, s, s + ro], [w] * 3)[1])
+            trip["w%d_one_launch_ms" % w] = (time.perf_counter() - t0) / 50 * 1e3
+            t0 = time.perf_counter()
+            ref = []
+            for (s, e), p, (l, r) in zip(spans[:50], pats[:50], halves):
+                ro = l.shape[1] / 12000.0
+                ref.append([dst.find_substream(p, s, w)[1], dst.find_substream(l, s, w)[1], dst.find_substream(r, s + ro, w)[1]])
+            trip["w%d_three_calls_ms" % w] = (time.perf_counter() - t0) / 50 * 1e3
+            assert got == ref
+            t0 = time.perf_counter()
+            for (s, e), p in zip(spans[:50], pats[:50]):
+                dst.find_substream(p, s, w)
+            trip["w%d_single_ms" % w] = (time.perf_counter() - t0) / 50 * 1e3
+            trip["w%d_triple_over_single" % w] = trip["w%d_one_launch_ms" % w] / trip["w%d_single_ms" % w]
         ev = [ScriptEvent(s, e) for s, e in spans]
         t0 = time.perf_counter()
         calculate_shifts(src, dst, [[x] for x in ev], 10, 30, 5)
@@ -49,7 +73,7 @@ def main():
         t_spec = time.perf_counter() - t0
         assert [(a.shift, a.diff) for a in ev] == [(a.shift, a.diff) for a in ev2]
         out[sample_type] = {"find_substream_w1.5_ms": t_small * 1e3, "find_substream_w10_ms": t_w10 * 1e3,
-                            "find_substreams_200x_w10_ms": t_batch * 1e3,
+                            "find_substreams_200x_w10_ms": t_batch * 1e3, "triple": trip,
                             "calculate_shifts_sequential_200_groups_ms": t_seq * 1e3,
                             "calculate_shifts_speculative_200_groups_ms": t_spec * 1e3,
                             "speculative_launches": proxy.launches, "requests": proxy.requests}
