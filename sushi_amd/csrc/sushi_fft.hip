@@ -2006,10 +2006,12 @@ void collect_kernel(IfftArgs a) {
                 // from 24 threads of every workgroup, the same-address atomics -- and a compare-and-swap loop among them -- were
                 // most of this kernel's time).  The candidate buffer's counter never runs far past its capacity: a workgroup that
                 // sees it full does not add to it (its tiles are evaluated at every position instead).
-                int total = 0, nt = 0, n_sparse = 0;
+                // (a listed tile goes to exact_tiles_kernel in entries of at most SPARSE_UNIT candidates: what an entry costs is
+                // bounded, and a workgroup's threads are all busy with it)
+                int total = 0, nt = 0, n_sparse = 0, extra = 0;
                 for (int t = 0; t < TILES_PER_PAIR; ++t) {
                     const int cnt = tcnt[t];
-                    if (cnt > 0) { ++nt; if (cnt <= SPARSE_MAX) { total += cnt; ++n_sparse; } }
+                    if (cnt > 0) { ++nt; if (cnt <= SPARSE_MAX) { total += cnt; ++n_sparse; extra += (cnt - 1) / SPARSE_UNIT; } }
                 }
                 if (nt > 0) {
                     int base = -1;
@@ -2017,7 +2019,8 @@ void collect_kernel(IfftArgs a) {
                         const int o = atomicAdd(&a.counters->n_cand, total);
                         if (o + total <= a.cand_cap) base = o;
                     }
-                    int slot = atomicAdd(&a.counters->n_tiles, nt);             // capacity: every tile of every pair
+                    // capacity: every tile of every pair + one entry per SPARSE_UNIT candidates of the candidate buffer
+                    int slot = atomicAdd(&a.counters->n_tiles, nt + (base >= 0 ? extra : 0));
                     for (int t = 0; t < TILES_PER_PAIR; ++t) {
                         const int cnt = tcnt[t];
                         if (cnt <= 0) continue;
@@ -2027,9 +2030,17 @@ void collect_kernel(IfftArgs a) {
                         TileDesc td;
                         td.search = s_idx;
                         td.p0 = (int)(rel0 + (int64_t)t * TILE);
-                        td.off = off;
-                        td.cnt = off >= 0 ? cnt : -1;
-                        a.tiles[slot++] = td;
+                        if (off >= 0) {
+                            for (int u = 0; u < cnt; u += SPARSE_UNIT) {
+                                td.off = off + u;
+                                td.cnt = cnt - u < SPARSE_UNIT ? cnt - u : SPARSE_UNIT;
+                                a.tiles[slot++] = td;
+                            }
+                        } else {
+                            td.off = -1;
+                            td.cnt = -1;
+                            a.tiles[slot++] = td;
+                        }
                     }
                     const int listed = base >= 0 || total == 0 ? n_sparse : 0;  // (all of the pair's sparse tiles are listed, or none)
                     if (listed > 0) {
@@ -2079,7 +2090,7 @@ inline WsLayout ws_layout(int64_t pairs, int64_t segs, int64_t searches) {
     w.pair_lb = o; o += align_up((size_t)pairs * sizeof(float), 256);
     w.pairmap = o; o += align_up((size_t)pairs * sizeof(int), 256);
     w.tconst = o; o += align_up((size_t)searches * sizeof(TemplConsts), 256);
-    w.tiles = o; o += align_up((size_t)pairs * TILES_PER_PAIR * sizeof(TileDesc), 256);
+    w.tiles = o; o += align_up(((size_t)pairs * TILES_PER_PAIR + (size_t)cand_capacity(pairs) / SPARSE_UNIT + 1) * sizeof(TileDesc), 256);
     w.candbuf = o; o += align_up((size_t)cand_capacity(pairs) * sizeof(int32_t), 256);
     w.dummy = o; o += align_up((size_t)MAC_DUMMY_LINES * MAC_THREADS * sizeof(uint4), 256);
     w.slb = o; o += align_up((size_t)pairs * sizeof(float), 256);

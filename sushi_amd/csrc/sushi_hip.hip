@@ -339,7 +339,7 @@ void exact_tiles_kernel(TileParams a) {
     __shared__ double ctot[SPARSE_TILE_MAX];          // sparse: the candidates' totals
     __shared__ int cpos[SPARSE_TILE_MAX];             // sparse: the candidates' positions, relative to the tile
     __shared__ unsigned long long red[4];
-    __shared__ int run_edge[2];
+    __shared__ int run_edge[2], next_item;
     static_assert(XRUN <= XG * SPARSE_TILE_MAX, "the chains share the chunk sums' space");
     const int n_tiles = a.counters->n_tiles;
     if (n_tiles == 0) return;
@@ -349,7 +349,14 @@ void exact_tiles_kernel(TileParams a) {
     // into XQ workgroups of one position per thread -- the chain of dependent multiply-adds a thread walks is a quarter as long.
     // Each position's sum is the same chain either way.
     const int split = n_tiles * 2 <= (int)gridDim.x ? XQ : 1;
-    for (int item = blockIdx.x; item < n_tiles * split; item += gridDim.x) {
+    // The entries cost from microseconds (a tile inside a run) to a millisecond (every position of a tile, a long pattern):
+    // the workgroups take them off a queue one at a time -- handed out in equal shares, some workgroups ran twice as long as others.
+    for (;;) {
+        __syncthreads();                                                // the previous entry's shared state is consumed
+        if (tid == 0) next_item = atomicAdd(&a.counters->tile_next, 1);
+        __syncthreads();
+        const int item = next_item;
+        if (item >= n_tiles * split) break;
         const int v = item / split, sub = item - v * split;
         const TileDesc td = a.tiles[v];
         const SearchDesc sd = a.searches[td.search];
@@ -364,7 +371,6 @@ void exact_tiles_kernel(TileParams a) {
         const T* __restrict__ Tp = (const T*)a.r.src_raw + sd.tmpl_off;
         const T* __restrict__ Ip = (const T*)a.r.dst_raw + (sd.win_start + p0);
         const int64_t room = a.r.dst_len - (sd.win_start + p0);         // samples of the stream from Ip on
-        __syncthreads();                                                // the previous tile's shared state is consumed
         if (tid < cnt) { cpos[tid] = a.cand[td.off + tid] - p0; ctot[tid] = 0.0; }
         const TemplStats ts = templ_stats(a.r.src_s1, a.r.src_s2, sd.tmpl_off, M, a.r.centre);
         const double* __restrict__ w1 = a.r.dst_s1 + sd.win_start;
@@ -445,19 +451,31 @@ void exact_tiles_kernel(TileParams a) {
         for (int c0 = 0; needs_corr && c0 < n_chunks; c0 += XG) {
             const int gc = min(XG, n_chunks - c0);
             const int m0 = c0 * XM;
-            const int gm = min(gc * XM, M - m0);                        // pattern samples of this group
             __syncthreads();                                            // previous group's reads are done (and part[] of the runs is written)
             const bool runs_only = c0 + gc <= na || c0 >= nb;           // (uniform)
             if (!runs_only) {
-#pragma unroll 4
-                for (int e = tid; e < gc * XM; e += 256) lt[(e / XM) * XMP + e % XM] = e < gm ? (double)Tp[m0 + e] : 0.0;     // zero padded: whole steps of 4
-                if (dense) {
-#pragma unroll 4
-                    for (int e = tid; e < span + gc * XM; e += 256) li[e] = (int64_t)m0 + e < room ? (double)Ip[m0 + e] : 0.0;
-                } else {
-#pragma unroll 4
-                    for (int e = tid; e < span + gc * XM; e += 256) li[skew(e)] = (int64_t)m0 + e < room ? (double)Ip[m0 + e] : 0.0;
-                }
+                // (staging: SB loads of a thread are requested together, from clamped addresses, and selected afterwards -- a
+                // conditional load per element came one after the other, a microsecond each, and was most of a sparse tile's time)
+                constexpr int SB = 8;
+                auto stage = [&](const T* __restrict__ src, const int64_t valid, const int n, auto put) {
+                    const int64_t last = valid > 0 ? valid - 1 : 0;
+                    for (int e0 = tid; e0 < n; e0 += SB * 256) {
+                        T x[SB];
+#pragma unroll
+                        for (int u = 0; u < SB; ++u) {
+                            const int64_t g = (int64_t)m0 + e0 + 256 * u;
+                            x[u] = src[g < last ? g : last];
+                        }
+#pragma unroll
+                        for (int u = 0; u < SB; ++u) {
+                            const int e = e0 + 256 * u;
+                            if (e < n) put(e, (int64_t)m0 + e < valid ? (double)x[u] : 0.0);
+                        }
+                    }
+                };
+                stage(Tp, (int64_t)M, gc * XM, [&](const int e, const double x) { lt[(e / XM) * XMP + e % XM] = x; });   // zero padded: whole steps of 4
+                if (dense) stage(Ip, room, span + gc * XM, [&](const int e, const double x) { li[e] = x; });
+                else stage(Ip, room, span + gc * XM, [&](const int e, const double x) { li[skew(e)] = x; });
                 __syncthreads();
             }
             if (dense) {
@@ -827,6 +845,7 @@ __global__ void reset_sub_kernel(int* sub_flagged, int* n_citems, RunCounters* c
     *sub_flagged = 0;
     *n_citems = 0;
     counters->n_tiles = 0;
+    counters->tile_next = 0;
     counters->n_cand = 0;
 }
 

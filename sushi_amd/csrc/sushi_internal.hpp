@@ -57,11 +57,12 @@ struct StreamRefs {
 
 // One exact-evaluation work item: TILE consecutive positions of one search, aligned to the absolute grid.
 constexpr int SPARSE_TILE_MAX = 256;   // candidates per tile up to which collect_kernel lists them; beyond: every position of the tile
+constexpr int SPARSE_UNIT = 64;        // a listed tile is handed to exact_tiles_kernel in entries of at most this many candidates
 struct TileDesc {
     int32_t search;       // global search index
     int32_t p0;           // first position of the tile relative to the search's window (may be < 0 for the first tile)
     int32_t off;          // sparse: first entry of the tile's candidate list in the candidate buffer
-    int32_t cnt;          // sparse: candidates; dense (every valid position of the tile): -1
+    int32_t cnt;          // sparse: candidates of this entry (<= SPARSE_UNIT: a tile of more is several entries); dense (every valid position of the tile): -1
 };
 
 // Counters of one run, in device memory (zeroed at the start of a run).
@@ -69,6 +70,7 @@ struct RunCounters {
     int32_t n_flagged;        // searches refine_kernel could not finish from the per-pair lists
     int32_t n_all_positions;  // of those: every position (bound violated)
     int32_t n_tiles;          // entries of the tile list (reset per sub-batch)
+    int32_t tile_next;        // exact_tiles_kernel's queue: the next entry to hand out (reset per sub-batch)
     int32_t n_cand;           // entries of the candidate buffer (reset per sub-batch)
     unsigned long long tiles_dense, tiles_sparse, candidates;    // totals of the run
     uint32_t max_ratio_bits;  // float bits of SushiHipBatchDiag.max_bound_ratio
