@@ -782,6 +782,47 @@ def test_hard_material_silence_tone_jingle_matches_oracle(oracle, sample_type):
     assert exact_positions < 0.2 * sum(npos[k] for k in range(len(events)) if d["flagged_per_search"][k])
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_runs_of_equal_samples_inside_at_the_ends_and_beyond_the_shortcut(oracle, dtype):
+    """Patterns cut from runs of ONE value (digital silence) tie over the whole run: dense tiles whose chunks lie inside a run
+    take the run's chunk chains instead of their positions' own sums (exact_tiles_kernel) -- same bits.  Here: tiles inside a
+    run and at both of its ends (the run starts and ends off the tile grid), a pattern of more chunks than the shortcut looks at
+    (every position evaluated, as before), and a run that reaches the end of the stream (tiles whose windows are cut there)."""
+    rng = np.random.default_rng(77)
+    n = 600000
+    if dtype == np.uint8:
+        dst = rng.integers(0, 256, n, dtype=np.uint8)
+        c = np.uint8(128)
+    else:
+        dst = rng.random(n, dtype=np.float32)
+        c = np.float32(0.5)
+    dst[100000:300000] = c
+    dst[560000:] = c
+    cuts = [(120000, 150000), (150000, 40000), (565000, 20000)]          # (first sample in dst, length)
+    offs, lens, parts = [], [], []
+    at = 0
+    for a, m in cuts:
+        t = dst[a:a + m].copy()
+        if dtype == np.uint8:
+            k = rng.random(m) < 0.1
+            t[k] = t[k] + rng.integers(-1, 2, int(k.sum())).astype(np.uint8)
+        else:
+            t += (rng.standard_normal(m) * 0.01).astype(np.float32)
+        offs.append(at); lens.append(m); parts.append(t)
+        at += m
+    src = np.concatenate(parts)
+    wst = [60000, 60000, 500000]
+    npos = [200000, 250000, n - 500000 - 20000 + 1]
+    (idx, score), b = _run_batch(dst, src, offs, lens, wst, npos, "fft", want_batch=True)
+    d = b.diagnostics()
+    assert d["flagged"] == 3 and d["all_positions"] == 0 and d["tiles_dense"] >= 48 + 150 + 18
+    for k in range(3):
+        res = oracle.match_template(dst[wst[k]:wst[k] + npos[k] + lens[k] - 1], src[offs[k]:offs[k] + lens[k]])[0]
+        (_check_u8 if dtype == np.uint8 else _check_f32)(res, idx[k], score[k])
+        # tens of thousands of positions score what the winner scores (to 2e-6): the ties of the run
+        assert int((res <= res[int(idx[k])] + 2e-6).sum()) >= (lens[k] == 150000 and 50001 or lens[k] == 40000 and 160001 or 20001)
+
+
 def test_one_accumulation_order_whatever_route_finds_the_position():
     """The exact value of a position is the same float32, bit for bit, whether the candidate lists (refine_kernel), a
     sparse tile or a dense tile (exact_tiles_kernel) evaluated it: delta = 1 makes every position a candidate and sends
