@@ -32,8 +32,9 @@
 extern "C" {
 #endif
 
-#define SUSHI_HIP_ABI_VERSION 10  /* 10: band-split exclusion (low-band rows + row norms behind the spectra, SUSHI_HIP_EXCLUDE_BAND / _WHOLE,
-                                     SushiHipBatchDiag.excluded_audited / .max_slb_ratio_excluded / .slb_violations / .band / .band_votes) */
+#define SUSHI_HIP_ABI_VERSION 11  /* 10: band-split exclusion (low-band rows + row norms behind the spectra, SUSHI_HIP_EXCLUDE_BAND / _WHOLE,
+                                     SushiHipBatchDiag.excluded_audited / .max_slb_ratio_excluded / .slb_violations / .band / .band_votes);
+                                     11: SushiHipBatchDiag.second_look_audited (appended) */
 
 #if defined(__GNUC__)
 #define SUSHI_HIP_API __attribute__((visibility("default")))
@@ -174,7 +175,11 @@ typedef struct SushiHipBatchDiag {
                                  would only be overhead; every 64th run looks again */
     int32_t band_votes[2];    /* what AUTO / ALWAYS decided the form from (first run of a batch): block pairs looked at, and those whose
                                  bound -- with nothing but the rows' norms outside the band -- already leaves room to exclude; the
-                                 band-split form is taken when that is >= 90 % */
+                                 band-split form is taken when that is >= 75 % */
+    int64_t second_look_audited; /* of excluded_audited: pairs the FIRST bound had let through and the second look (band-split form:
+                                 the low band's samples themselves) then excluded -- a hashed 1/32 of them per run
+                                 (1/16 with SUSHI_HIP_AUDIT_EVERY=1, none with 0), other ones every run -- transformed all the same and
+                                 held to what they really score, like the others */
 } SushiHipBatchDiag;
 
 typedef struct SushiHipBatch SushiHipBatch;

@@ -22,7 +22,7 @@ METHODS = {"sqdiff_normed": METHOD_SQDIFF_NORMED, "ccoeff_normed": METHOD_CCOEFF
 VIEW_XC, VIEW_S1, VIEW_S2, VIEW_UREL, VIEW_BASE, VIEW_SPECTRA, VIEW_USREL, VIEW_BASE1, VIEW_COARSE, VIEW_SPECTRA_LOW, \
     VIEW_ZNORM_REST = range(11)
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 NSTAGES = 6
 STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish", "bound")
 STAGE_KERNELS = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "mac_list_kernel+mac_rows_kernel+ifft_kernel", "refine": "refine_kernel",
@@ -53,7 +53,7 @@ class BatchDiag(ctypes.Structure):
                 ("max_bound_ratio_noncandidate", ctypes.c_float), ("audited", ctypes.c_int64),
                 ("pairs_transformed", ctypes.c_int64), ("excluded_audited", ctypes.c_int64),
                 ("max_slb_ratio_excluded", ctypes.c_float), ("slb_violations", ctypes.c_int32), ("band", ctypes.c_int32),
-                ("suspended", ctypes.c_int32), ("band_votes", ctypes.c_int32 * 2)]
+                ("suspended", ctypes.c_int32), ("band_votes", ctypes.c_int32 * 2), ("second_look_audited", ctypes.c_int64)]
 
 
 _lib = None

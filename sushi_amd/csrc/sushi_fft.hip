@@ -1214,13 +1214,15 @@ __device__ __forceinline__ void ifft_one(const IfftArgs& a, const int slot, floa
             // (TM_SQDIFF_NORMED scores are clamped at 1, cv2's rule, the bound is not: a pair far louder than the pattern has
             // a bound in the thousands and every score 1)
             const float s = METHOD == SUSHI_HIP_METHOD_CCOEFF_NORMED ? a.slb[pr] : fminf(a.slb[pr], 1.0f), ub = lmin_s + e_pair;
-            const bool audit = a.audit_mark && (a.audit_mark[pr] & 1);
+            const unsigned char am = a.audit_mark ? a.audit_mark[pr] : (unsigned char)0;
+            const bool audit = (am & 1) != 0;
             if (s > ub * 1.00001f + 1e-7f) {
                 a.viol[a.first_search + k] = 1;
                 atomicAdd(&a.counters->slb_violations, 1);
             }
             if (audit) {
                 atomicAdd(&a.counters->excluded_audited, 1ull);
+                if (am & 4) atomicAdd(&a.counters->second_look_audited, 1ull);
                 const float ratio = s > 0.f ? s / fmaxf(ub, 1e-30f) : 0.f;
                 if (__float_as_uint(ratio) > *(volatile uint32_t*)&a.counters->max_slb_ratio_bits)
                     atomicMax(&a.counters->max_slb_ratio_bits, __float_as_uint(ratio));
@@ -1354,7 +1356,7 @@ struct BoundArgs {
     const float* znorm_rest;          // [3][norm_stride] block spectra: norm outside the band of Z, of its real block at j B, of the one H on
     int64_t norm_stride;
     int* band_votes;                  // [2] prediction: pairs looked at, pairs whose bound leaves room
-    unsigned char* audit_mark;        // [pairs of the sub-batch] bit 0 = excluded, transformed all the same (the audit of the exclusion); bit 1 = listed
+    unsigned char* audit_mark;        // [pairs of the sub-batch] bit 0 = excluded, transformed all the same (the audit of the exclusion); bit 1 = listed; bit 2 = excluded by the second look
     unsigned audit_seq;               // changes from run to run: which excluded pair of a search is audited
     int audit_every;                  // one search in this many is audited per run (0: none)
     const int* list;                  // slb_list_kernel / bound_low_exact_kernel / survivor2_kernel: the pairs the first bound left ...
@@ -1909,9 +1911,16 @@ void survivor2_kernel(BoundArgs a) {
                 const unsigned long long g = a.gkeys[a.first_search + k];
                 const float U = g == NO_KEY ? __builtin_inff() : key_score(g);
                 if (U < 0.9999f && a.slb[pr] > U * 1.000001f + 1e-7f) {
-                    keep = false;
-                    a.pair_lb[pr] = __builtin_inff();
-                    a.audit_mark[pr] = 0;
+                    // the audit of THIS bound: a hashed sample of the pairs it excludes -- other ones every run -- stays listed, is
+                    // transformed all the same, and ifft_kernel holds the pair's (second) lower bound to what it really scores
+                    const unsigned h = ((unsigned)(a.sub_first_pair + pr) * 2654435761u + a.audit_seq * 40503u) >> 11;
+                    if (a.audit_every > 0 && h % (16u * (unsigned)a.audit_every) == 0u) {
+                        a.audit_mark[pr] = 1 | 2 | 4;                   // audited, listed, by the second look
+                    } else {
+                        keep = false;
+                        a.pair_lb[pr] = __builtin_inff();
+                        a.audit_mark[pr] = 0;
+                    }
                 }
             }
         }
@@ -2883,6 +2892,7 @@ int sushi_hip_batch_diagnostics(SushiHipBatch* b, SushiHipBatchDiag* diag, float
     diag->band = b->last_band;
     diag->suspended = b->last_suspended;
     diag->band_votes[0] = b->band_votes[0]; diag->band_votes[1] = b->band_votes[1];
+    diag->second_look_audited = (int64_t)c.second_look_audited;
     std::vector<int32_t> fl((size_t)b->n);
     if (hipMemcpy(fl.data(), b->mem + b->lay.flags, (size_t)b->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
         return SUSHI_HIP_ELAUNCH;

@@ -80,6 +80,7 @@ struct RunCounters {
     unsigned long long excluded_audited;    // of those: pairs the bound HAD excluded, transformed as a check of the bound
     uint32_t max_slb_ratio_bits;            // float bits: largest (lower bound / upper bound of the pair's real best score) over the audited excluded pairs
     int32_t slb_violations;                 // pairs whose lower bound turned out above a real score (their searches go to every position)
+    unsigned long long second_look_audited; // of excluded_audited: pairs the second look had excluded (survivor2_kernel's sample)
 };
 
 int direct_variant_count();

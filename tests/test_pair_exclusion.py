@@ -72,6 +72,39 @@ def test_almost_every_pair_is_excluded_and_the_results_are_the_oracles(oracle, m
         assert abs(float(score[k]) - osc) <= 1e-4 * abs(osc) + 2.5e-7
 
 
+def test_the_second_look_is_audited_too(monkeypatch):
+    """Band-split form: the pairs the first bound lets through get a second, sharper one (the low band's samples themselves), which
+    drops most of them before their whole rows are formed.  A hashed sample of the pairs IT drops -- other ones every run -- is
+    transformed all the same and the second bound held to what they really score (second_look_audited, a part of
+    excluded_audited): over a few dozen runs, with every search audited, that is dozens of pairs, none above its real score,
+    the results the same bits every run."""
+    monkeypatch.setenv("SUSHI_HIP_AUDIT_EVERY", "1")
+    n = 60 * PAIR
+    dst = _stream(n, 5)
+    rng = np.random.default_rng(6)
+    src = (dst + rng.standard_normal(n).astype(np.float32) * 0.02).clip(0, 1).astype(np.float32)
+    offs, lens, wst, npos = [], [], [], []
+    for k in range(48):
+        m = int(rng.integers(6000, 30000))                        # short patterns: the ones the first bound leaves pairs of
+        a = int(rng.integers(20 * PAIR, n - 20 * PAIR - m))
+        ws = a - int(rng.integers(2 * PAIR, 15 * PAIR))
+        offs.append(a); lens.append(m); wst.append(ws); npos.append(30 * PAIR + int(rng.integers(0, 5000)))
+    idx, score, b = _run(dst, src, offs, lens, wst, npos, exclusion="band")
+    ref = (idx.copy(), score.copy().view(np.uint32))
+    second, first, worst = 0, 0, 0.0
+    for r in range(40):
+        b.run()
+        idx, score = b.results()
+        d = b.diagnostics()
+        assert d["slb_violations"] == 0 and d["all_positions"] == 0 and d["band"] == 1
+        assert (idx == ref[0]).all() and (score.view(np.uint32) == ref[1]).all()
+        assert 0 <= d["second_look_audited"] <= d["excluded_audited"]
+        second += d["second_look_audited"]; first += d["excluded_audited"] - d["second_look_audited"]
+        worst = max(worst, d["max_slb_ratio_excluded"])
+    assert second >= 20 and first >= 40 * 24 and 0.0 < worst < 1.0, (second, first, worst)
+    assert [int(i) for i in idx] == [o - w for o, w in zip(offs, wst)]
+
+
 def test_match_on_a_pair_boundary_and_at_both_ends_of_the_window(oracle):
     n = 30 * PAIR
     dst = _stream(n, 3)
