@@ -72,25 +72,41 @@ def test_almost_every_pair_is_excluded_and_the_results_are_the_oracles(oracle, m
         assert abs(float(score[k]) - osc) <= 1e-4 * abs(osc) + 2.5e-7
 
 
+def _audio_like_job(n_events=40, seconds=360.0, window=60.0, off=2.25):
+    """The bench's kind of material (sushi_amd.synth: band-limited, audio-like) at a size a test can afford."""
+    from sushi_amd import synth
+    from sushi_amd.wav import WavStream
+    rate = 12000
+    dst_pcm = synth.make_dst_pcm(seconds, rate, seed=31)
+    src_pcm = synth.make_src_pcm(dst_pcm, int(off * rate), seed=32)
+    dst = WavStream.from_samples(dst_pcm, rate, sample_rate=rate, sample_type="float32")
+    src = WavStream.from_samples(src_pcm, rate, sample_rate=rate, sample_type="float32")
+    events = synth.make_events(n_events, seconds, window + off, seed=33)              # 1 - 5 s, as the bench's
+    pats, centres, wins = synth.explicit_descriptors(src, dst, events, off, window, seed=34)
+    offs = [src._get_sample_for_time(s) for s, _ in events]
+    lens = [p.shape[1] for p in pats]
+    wst, npos = [], []
+    for m, c, w in zip(lens, centres, wins):
+        _, lo, p = dst._window(m, c, w)
+        wst.append(lo); npos.append(p)
+    planted = [o + int(off * rate) - w for o, w in zip(offs, wst)]
+    return dst, src, offs, lens, wst, npos, planted
+
+
 def test_the_second_look_is_audited_too(monkeypatch):
     """Band-split form: the pairs the first bound lets through get a second, sharper one (the low band's samples themselves), which
     drops most of them before their whole rows are formed.  A hashed sample of the pairs IT drops -- other ones every run -- is
     transformed all the same and the second bound held to what they really score (second_look_audited, a part of
     excluded_audited): over a few dozen runs, with every search audited, that is dozens of pairs, none above its real score,
     the results the same bits every run."""
+    from sushi_amd.device import SearchBatch
     monkeypatch.setenv("SUSHI_HIP_AUDIT_EVERY", "1")
-    n = 60 * PAIR
-    dst = _stream(n, 5)
-    rng = np.random.default_rng(6)
-    src = (dst + rng.standard_normal(n).astype(np.float32) * 0.02).clip(0, 1).astype(np.float32)
-    offs, lens, wst, npos = [], [], [], []
-    for k in range(48):
-        m = int(rng.integers(6000, 30000))                        # short patterns: the ones the first bound leaves pairs of
-        a = int(rng.integers(20 * PAIR, n - 20 * PAIR - m))
-        ws = a - int(rng.integers(2 * PAIR, 15 * PAIR))
-        offs.append(a); lens.append(m); wst.append(ws); npos.append(30 * PAIR + int(rng.integers(0, 5000)))
-    idx, score, b = _run(dst, src, offs, lens, wst, npos, exclusion="band")
+    dst, src, offs, lens, wst, npos, planted = _audio_like_job()
+    b = SearchBatch(dst.device_stream(), src.device_stream(), offs, lens, wst, npos, path="fft", exclusion="band")
+    b.run()
+    idx, score = b.results()
     ref = (idx.copy(), score.copy().view(np.uint32))
+    assert all(abs(int(i) - p) <= 1 for i, p in zip(idx, planted))
     second, first, worst = 0, 0, 0.0
     for r in range(40):
         b.run()
@@ -98,11 +114,10 @@ def test_the_second_look_is_audited_too(monkeypatch):
         d = b.diagnostics()
         assert d["slb_violations"] == 0 and d["all_positions"] == 0 and d["band"] == 1
         assert (idx == ref[0]).all() and (score.view(np.uint32) == ref[1]).all()
-        assert 0 <= d["second_look_audited"] <= d["excluded_audited"]
+        assert 0 <= d["second_look_audited"] <= d["excluded_audited"] < d["pairs_transformed"] < b.fft_pairs // 5, (d, b.fft_pairs)
         second += d["second_look_audited"]; first += d["excluded_audited"] - d["second_look_audited"]
         worst = max(worst, d["max_slb_ratio_excluded"])
-    assert second >= 20 and first >= 40 * 24 and 0.0 < worst < 1.0, (second, first, worst)
-    assert [int(i) for i in idx] == [o - w for o, w in zip(offs, wst)]
+    assert second >= 20 and first >= 40 * 20 and 0.0 < worst < 1.0, (second, first, worst)
 
 
 def test_match_on_a_pair_boundary_and_at_both_ends_of_the_window(oracle):
