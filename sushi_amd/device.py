@@ -6,9 +6,12 @@ all arithmetic is in libsushi_hip.so, behind the two handles of its C ABI (inclu
   once per stream.
 * ``SearchBatch``   -- a batch of (pattern, window) requests resident in HBM (``SushiHipBatch``); ``run()`` is one
   pass of the hot path and nothing else.
+* ``warm_up``       -- the process's one-time GPU start-up (context, code object), paid when the caller chooses.
 """
 import ctypes
 import os
+import threading
+import time
 
 import numpy as np
 import torch
@@ -26,6 +29,49 @@ def _require_gpu(device=None):
     return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
 
 
+_warm = {"thread": None, "done": False, "ms": None, "error": None}
+_warm_lock = threading.Lock()
+
+
+def warm_up(device=None, background=False):
+    """Pay this process's one-time GPU start-up NOW: the HIP context's first real use and the load of the library's code
+    object -- 0.09-0.15 s that otherwise sit in front of the first stream (tools/setup_probe.py: a 64 K-sample stream costs 93 ms
+    as the first call of a process, a 2-h stream 8 ms as a later one).  A one-shot job calls it first thing, with
+    background=True, and has it behind itself by the time its audio is demuxed / decoded (the reference spends seconds there,
+    sushi.py:649-650 ffmpeg demux); a later call -- or the first DeviceStream -- waits for it.  Idempotent; returns the milliseconds the
+    start-up took (None while a background one is still running).  Do not fork after calling it."""
+    with _warm_lock:
+        if _warm["thread"] is None:
+            def work():
+                t0 = time.perf_counter()
+                try:
+                    dev = _require_gpu(device)
+                    with torch.cuda.device(dev):
+                        tiny = DeviceStream(np.linspace(0.0, 1.0, 65536, dtype=np.float32), device=dev, _wait_for_warm_up=False)
+                        tiny.searchable()
+                        torch.cuda.synchronize(dev)
+                except Exception as e:                  # (the real call that follows raises the same, where it can be handled)
+                    _warm["error"] = e
+                _warm["ms"] = (time.perf_counter() - t0) * 1e3
+                _warm["done"] = True
+            _warm["thread"] = threading.Thread(target=work, name="sushi_amd-warm-up", daemon=True)
+            _warm["thread"].start()
+        t = _warm["thread"]
+    if background:
+        return _warm["ms"] if _warm["done"] else None
+    t.join()
+    if _warm["error"] is not None:
+        raise _warm["error"]
+    return _warm["ms"]
+
+
+def _join_warm_up():
+    """A warm-up in flight finishes before anything else touches the GPU (its errors are the real call's to raise)."""
+    t = _warm["thread"]
+    if t is not None and not _warm["done"] and t is not threading.current_thread():
+        t.join()
+
+
 def _raw_stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -41,10 +87,12 @@ def _buffer(nbytes, device):
 class DeviceStream(object):
     """HBM-resident, match-ready form of a 1-D sample row (uint8 or float32)."""
 
-    def __init__(self, samples, device=None):
+    def __init__(self, samples, device=None, _wait_for_warm_up=True):
         """`samples`: a host array (1-D or (1, N), uint8 / float32) -- uploaded -- or a 1-D torch tensor
         of those dtypes that already lives on the GPU (used as is)."""
         self._handle = None
+        if _wait_for_warm_up:
+            _join_warm_up()
         on_device = isinstance(samples, torch.Tensor)
         if on_device:
             if samples.dim() != 1 or not samples.is_cuda or not samples.is_contiguous():
