@@ -276,6 +276,10 @@ class SearchBatch(object):
             _native.check(L.sushi_hip_batch_set_exclusion(h, _native.EXCLUSION[exclusion]), "sushi_hip_batch_set_exclusion")
             self.out_idx = torch.empty(n, dtype=torch.int32, device=dev)
             self.out_score = torch.empty(n, dtype=torch.float32, device=dev)
+            # (index, score bits) records as well, written by the library's last kernel: results() is then ONE copy to the
+            # host instead of two -- a fifth of what a drop-in call waits for its answer (tools/call_breakdown.py)
+            self._packed = None
+            self.set_packed_output(torch.empty((n, 2), dtype=torch.int32, device=dev))
         info = _native.BatchInfo()
         _native.check(L.sushi_hip_batch_info(h, ctypes.byref(info)), "sushi_hip_batch_info")
         self.variant = int(info.variant)
@@ -324,6 +328,9 @@ class SearchBatch(object):
 
     def results(self):
         """(idx int32 ndarray, score float32 ndarray) -- synchronises."""
+        if self._packed is not None:
+            rec = self._packed[:self.n].cpu().numpy()
+            return np.ascontiguousarray(rec[:, 0]), np.ascontiguousarray(rec[:, 1]).view(np.float32)
         return self.out_idx.cpu().numpy(), self.out_score.cpu().numpy()
 
     def diagnostics(self, per_search=False):
