@@ -232,15 +232,30 @@ class SearchBatch(object):
         n = tmpl_off.shape[0]
         if not (tmpl_len.shape[0] == win_start.shape[0] == n_pos.shape[0] == n) or n == 0:
             raise SushiError("descriptor arrays must be non-empty and of equal length")
-        if (tmpl_len < 1).any():
+        if n <= 4:
+            # (a drop-in call is a batch of one, a triple one of three: a dozen NumPy reductions over one element each were a
+            # tenth of such a call -- tools/call_breakdown.py; the same checks in the same order on plain ints)
+            o_, m_, w_, p_ = tmpl_off.tolist(), tmpl_len.tolist(), win_start.tolist(), n_pos.tolist()
+            empty = any(m < 1 for m in m_)
+            too_long = any(p < 1 for p in p_)
+            bad_src = any(o < 0 or o + m > src.n for o, m in zip(o_, m_))
+            bad_dst = any(w < 0 or w + p + m - 1 > dst.n for w, p, m in zip(w_, p_, m_))
+            too_large = any(p > 0x7fffffff - 65536 or m > 0x7fffffff - 65536 for p, m in zip(p_, m_))
+        else:
+            empty = bool((tmpl_len < 1).any())
+            too_long = bool((n_pos < 1).any())
+            bad_src = bool((tmpl_off < 0).any() or (tmpl_off + tmpl_len > src.n).any())
+            bad_dst = bool((win_start < 0).any() or (win_start + n_pos + tmpl_len - 1 > dst.n).any())
+            too_large = bool((n_pos > 0x7fffffff - 65536).any() or (tmpl_len > 0x7fffffff - 65536).any())
+        if empty:
             raise SushiError("empty pattern")
-        if (n_pos < 1).any():
+        if too_long:
             raise SushiError("pattern is longer than the search window (cv2.error in the reference)")
-        if (tmpl_off < 0).any() or (tmpl_off + tmpl_len > src.n).any():
+        if bad_src:
             raise SushiError("pattern slice outside the source stream")
-        if (win_start < 0).any() or (win_start + n_pos + tmpl_len - 1 > dst.n).any():
+        if bad_dst:
             raise SushiError("search window outside the destination stream")
-        if (n_pos > 0x7fffffff - 65536).any() or (tmpl_len > 0x7fffffff - 65536).any():
+        if too_large:
             raise SushiError("search too large")
         self.n = n
         self.path = default_path() if path is None else path
