@@ -297,6 +297,10 @@ def main():
     ap.add_argument("--ws-mb", type=int, default=None, help="FFT path scratch per batch (MiB); default: what one "
                                                             "sub-batch for the whole shard needs, at most 160 GiB")
     ap.add_argument("--delta", type=float, default=None)
+    ap.add_argument("--emulate-shards", type=int, default=8,
+                    help="N = 1 only: after the measurement, cut the job into the G = 2, 4, .. work-balanced shards the G-rank run "
+                         "would give its ranks (up to this G; 0 = off) and time every shard on THIS GPU -- the slowest shard is "
+                         "what a G-GPU step would take, the collective aside (`shard_emulation` in the line)")
     ap.add_argument("--dry-backend", choices=("gloo",), default=None,
                     help="no GPU: run this file's N-rank control flow over gloo with a stand-in batch (tests only)")
     ap.add_argument("--dry-plant-error", type=int, default=0,
@@ -544,6 +548,45 @@ def main():
     idx_all = idx_all.cpu().numpy()
     score_all = score_all.cpu().numpy()
 
+    # ---- what a G-rank run would give each of its ranks, timed on this one GPU ----
+    shard_emulation = None
+    if world == 1 and not dry and args.emulate_shards >= 2 and not args.profile_only:
+        from sushi_amd.distributed import weighted_bounds
+        w_all = search_work(wst, npos, lens, args.path)
+        shard_emulation = {"label": "single-GPU shard emulation: every shard of the G-rank job timed alone on this GPU with the "
+                                    "streams resident; the all-gather (8 B per event) and xGMI are NOT in it",
+                           "one_gpu_ms_per_step": kernel_ms, "by_world_size": {}}
+        g = 2
+        while g <= args.emulate_shards:
+            rows = []
+            for r, (lo, hi) in enumerate(weighted_bounds(w_all, g)):
+                sb = make_batch(lo, hi)
+                for _ in range(2):
+                    sb.run()
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 8
+                t_h = time.perf_counter()
+                e0.record()
+                for _ in range(reps):
+                    sb.run()
+                e1.record()
+                host_ms = (time.perf_counter() - t_h) / reps * 1e3       # the launch chain of one run() on the host
+                torch.cuda.synchronize(dev)
+                ms = e0.elapsed_time(e1) / reps
+                si, _ = sb.results()
+                ok = bool((si == idx_all[lo:hi]).all())
+                rows.append({"rank": r, "events": hi - lo, "work_over_mean": round(float(w_all[lo:hi].sum() / (w_all.sum() / g)), 4),
+                             "ms_per_step": round(ms, 4), "host_launch_ms": round(host_ms, 4), "same_results_as_the_one_gpu_run": ok})
+                del sb
+            worst = max(x["ms_per_step"] for x in rows)
+            shard_emulation["by_world_size"][str(g)] = {
+                "max_shard_ms": worst, "mean_shard_ms": round(float(np.mean([x["ms_per_step"] for x in rows])), 4),
+                "implied_events_per_s_gather_excluded": n_total / (worst * 1e-3),
+                "implied_speedup_over_one_gpu": kernel_ms / worst, "shards": rows}
+            torch.cuda.empty_cache()
+            g *= 2
+
     if rank == 0:
         # parity on the whole job: planted offset recovered to +-1 sample on every (ordinary) event
         times = np.array(start_times) + idx_all.astype(np.float64) / float(rate)
@@ -742,6 +785,8 @@ def main():
             out["dry_run"] = "control flow only (--dry-backend %s): `value` is not a measurement" % args.dry_backend
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if shard_emulation is not None:
+            out["shard_emulation"] = shard_emulation
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

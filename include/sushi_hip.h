@@ -32,9 +32,11 @@
 extern "C" {
 #endif
 
-#define SUSHI_HIP_ABI_VERSION 11  /* 10: band-split exclusion (low-band rows + row norms behind the spectra, SUSHI_HIP_EXCLUDE_BAND / _WHOLE,
+#define SUSHI_HIP_ABI_VERSION 12  /* 10: band-split exclusion (low-band rows + row norms behind the spectra, SUSHI_HIP_EXCLUDE_BAND / _WHOLE,
                                      SushiHipBatchDiag.excluded_audited / .max_slb_ratio_excluded / .slb_violations / .band / .band_votes);
-                                     11: SushiHipBatchDiag.second_look_audited (appended) */
+                                     11: SushiHipBatchDiag.second_look_audited (appended);
+                                     12: sushi_hip_batch_set_bound_model (the excluded side of the pair exclusion is a worst-case bound by
+                                     default), the band is |f| < N/8 strictly (bin 7N/8 of a low row is zero and counted with the rest) */
 
 #if defined(__GNUC__)
 #define SUSHI_HIP_API __attribute__((visibility("default")))
@@ -85,7 +87,7 @@ SUSHI_HIP_API int sushi_hip_device_ok(void);
  *              as packed halves (float16 re, float16 im: 4 bytes per bin) times one power of two per stream, bin f at
  *              sushi_hip_fft_slot_of_bin(f), followed by one all-zero block:
  *              (nb + 1) * N * 4 bytes; behind them, for the band-split form of the pair exclusion:
- *              the LOW BAND (bins f < N/8 and f >= 7N/8) of every block spectrum once more, (nb + 1) * N bytes, in the order
+ *              the LOW BAND (bins |f| < N/8; the slot of bin 7N/8 is zero) of every block spectrum once more, (nb + 1) * N bytes, in the order
  *              the bound's transform loads it, and float32[nb + 1]: the norm of each block spectrum's stored halves
  *              OUTSIDE that band.  sushi_hip_stream_spectra_bytes(n) is the sum.
  * A stream that is only a source of patterns does not need spectra. */
@@ -217,6 +219,15 @@ SUSHI_HIP_API int sushi_hip_batch_set_method(SushiHipBatch* batch, int method);
 #define SUSHI_HIP_EXCLUDE_BAND 3
 #define SUSHI_HIP_EXCLUDE_WHOLE 4
 SUSHI_HIP_API int sushi_hip_batch_set_exclusion(SushiHipBatch* batch, int mode);
+/* How the roundings of the stored spectra and products (packed halves) enter the LOWER BOUND by which a block pair is excluded
+ * without being transformed.  WORST_CASE (default after create): every rounding at its largest, all of them in phase -- triangle
+ * inequality over the bins, Cauchy-Schwarz, a proven error bound of the float32 transforms; no independence is assumed, so a
+ * pair is excluded only if NO position of it can reach the search's minimum.  STATISTICAL: round 5's model (8
+ * standard deviations of independent roundings), kept for A/B measurements.  Results are the same either way wherever the
+ * model holds; what differs is how many pairs are left to transform. */
+#define SUSHI_HIP_BOUND_WORST_CASE 0
+#define SUSHI_HIP_BOUND_STATISTICAL 1
+SUSHI_HIP_API int sushi_hip_batch_set_bound_model(SushiHipBatch* batch, int model);
 /* Multi-GPU callers: every following run ALSO writes its results as n 8-byte records (int32 index, float32 score bits) to
  * out_packed_dev (8-byte aligned, n records; NULL = off) -- the block a rank contributes to the one all-gather of the path, written
  * by the kernel that writes out_idx / out_score instead of by two copies afterwards. */

@@ -22,12 +22,13 @@ METHODS = {"sqdiff_normed": METHOD_SQDIFF_NORMED, "ccoeff_normed": METHOD_CCOEFF
 VIEW_XC, VIEW_S1, VIEW_S2, VIEW_UREL, VIEW_BASE, VIEW_SPECTRA, VIEW_USREL, VIEW_BASE1, VIEW_COARSE, VIEW_SPECTRA_LOW, \
     VIEW_ZNORM_REST = range(11)
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 NSTAGES = 6
 STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish", "bound")
 STAGE_KERNELS = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "mac_list_kernel+mac_rows_kernel+ifft_kernel", "refine": "refine_kernel",
                  "finish": "collect_kernel+exact_tiles_kernel+unpack_keys_kernel", "bound": "bound_low_kernel|bound_kernel"}
 EXCLUSION = {"auto": 0, "always": 1, "never": 2, "band": 3, "whole": 4}        # SUSHI_HIP_EXCLUDE_*
+BOUND_MODEL = {"worst_case": 0, "statistical": 1}                              # SUSHI_HIP_BOUND_*
 # every kernel a stage's HIP-event span covers (profiles/pmc_traffic.json is keyed by kernel)
 STAGE_KERNEL_SETS = {"tspec": ("tspec_kernel",), "mac": ("mac_kernel", "mac_long_kernel"),
                      "ifft": ("ifft_kernel", "ifft_list_kernel", "pilot_kernel", "survivor_kernel", "mac_list_kernel", "mac_rows_kernel",
@@ -125,6 +126,8 @@ def lib():
     L.sushi_hip_batch_set_packed_output.argtypes = [vp, vp]
     L.sushi_hip_batch_set_exclusion.restype = ci
     L.sushi_hip_batch_set_exclusion.argtypes = [vp, ci]
+    L.sushi_hip_batch_set_bound_model.restype = ci
+    L.sushi_hip_batch_set_bound_model.argtypes = [vp, ci]
     L.sushi_hip_batch_pair_bounds.restype = ci
     L.sushi_hip_batch_pair_bounds.argtypes = [vp, vp, vp, ctypes.POINTER(i64)]
     L.sushi_hip_batch_destroy.restype = None

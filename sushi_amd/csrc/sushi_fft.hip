@@ -169,7 +169,10 @@ __device__ __attribute__((aligned(16))) const unsigned g_dft16_bl[2 * 64 * 2] = 
 // is r = 0, 1, 14, 15 of every thread -- one 16-byte entry of the low row (fft_core.hpp lslot_of_thread) --, and of the other
 // twelve bins the energy of the halves AS STORED is summed: |sum over the bins outside the band of Tt_s(f) Z_j(f)| is at most
 // the product of the two rows' norms outside the band (Cauchy-Schwarz), whatever the phases.
-__device__ __forceinline__ uint4 low_entry_and_rest(const cpx (&v)[sushi_fft::PER], const float sc, float& rest2) {
+// The band is kept MIRROR-SYMMETRIC: bin 7N/8 (thread 0's register 14) has its mirror N/8 outside the band, so it is counted with
+// the rest -- its low-row entry is zero and its energy goes to the norm -- and the band is |f| < N/8 strictly.  slb_kernel's split
+// of the rest into the two real blocks' parts (real_block_rest_norms) holds over a mirror-symmetric set of bins only.
+__device__ __forceinline__ uint4 low_entry_and_rest(const cpx (&v)[sushi_fft::PER], const float sc, const int tid, float& rest2) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     float e = 0.f;
 #pragma unroll
@@ -177,9 +180,14 @@ __device__ __forceinline__ uint4 low_entry_and_rest(const cpx (&v)[sushi_fft::PE
         const h2 h = __builtin_bit_cast(h2, pack_h2(v[r].x * sc, v[r].y * sc));
         e = __builtin_amdgcn_fdot2(h, h, e, false);
     }
+    unsigned e14 = pack_h2(v[14].x * sc, v[14].y * sc);
+    if (tid == 0) {
+        const h2 h = __builtin_bit_cast(h2, e14);
+        e = __builtin_amdgcn_fdot2(h, h, e, false);
+        e14 = 0u;
+    }
     rest2 = e;
-    return uint4{pack_h2(v[0].x * sc, v[0].y * sc), pack_h2(v[1].x * sc, v[1].y * sc), pack_h2(v[14].x * sc, v[14].y * sc),
-                 pack_h2(v[15].x * sc, v[15].y * sc)};
+    return uint4{pack_h2(v[0].x * sc, v[0].y * sc), pack_h2(v[1].x * sc, v[1].y * sc), e14, pack_h2(v[15].x * sc, v[15].y * sc)};
 }
 // the low entries of a workgroup into their row (whole KiB per wave through the LDS) and the norm of the rest (red: FT / 64 floats)
 __device__ __forceinline__ float wave_sum_shfl(float w) {
@@ -228,8 +236,11 @@ __device__ __forceinline__ void real_block_rest_norms(const cpx (&v)[sushi_fft::
         const h2 m = __builtin_bit_cast(h2, w[(pr - 1) * FT + pt]);
         const float ar = (float)z.x + (float)m.x, ai = (float)z.y - (float)m.y;      // Z(f) + conj Z(N - f)
         const float br = (float)z.x - (float)m.x, bi = (float)z.y + (float)m.y;      // Z(f) - conj Z(N - f)
-        sa += ar * ar + ai * ai;
-        sb += br * br + bi * bi;
+        // (bin 7N/8 -- thread 0's register 14, counted with the rest: low_entry_and_rest -- is the mirror of bin N/8, thread 0's
+        // register 2: the same moduli once more)
+        const float twice = tid == 0 && r == 2 ? 2.f : 1.f;
+        sa += twice * (ar * ar + ai * ai);
+        sb += twice * (br * br + bi * bi);
     }
     sa = wave_sum_shfl(sa); sb = wave_sum_shfl(sb);
     __syncthreads();
@@ -272,7 +283,7 @@ void spectra_kernel(const T* __restrict__ raw, int64_t n, uint32_t* __restrict__
     }
     sushi_fft::fft_split<FFT_LOGN, -1>(v, tid, lds, tw);
     float rest2;
-    const uint4 low = low_entry_and_rest(v, sz, rest2);
+    const uint4 low = low_entry_and_rest(v, sz, tid, rest2);
     real_block_rest_norms(v, sz, tid, lds, red, znorm_rest + norm_stride + j, znorm_rest + 2 * norm_stride + j);
     to_load_order(v, tid, lds);
     uint4* __restrict__ out = reinterpret_cast<uint4*>(spec + (size_t)j * FN);
@@ -329,7 +340,6 @@ struct TspecArgs {
     int method;                       // SUSHI_HIP_METHOD_CCOEFF_NORMED: spectra of the pattern minus its own mean
     uint4* tspec_low;                 // [segments of the sub-batch][LROWE] the low band again, in bound_low_kernel's order
     float* tnorm_rest;                // [segments of the sub-batch] SQUARED norm of the stored halves outside the band (accumulated: zero it first)
-    int dbg;                          // development only (SUSHI_HIP_TSPEC_DBG): 1 no low store, 2 no norm atomic, 4 no norm at all
 };
 
 template <typename T>
@@ -380,9 +390,8 @@ void tspec_kernel(TspecArgs a) {
     }
     sushi_fft::fft_split<FFT_LOGN, -1>(v, tid, lds, tw);
     const float sc = t_scale / (float)FN;
-    float rest2 = 0.f;
-    uint4 low = uint4{0u, 0u, 0u, 0u};
-    if (!(a.dbg & 4)) low = low_entry_and_rest(v, sc, rest2);
+    float rest2;
+    const uint4 low = low_entry_and_rest(v, sc, tid, rest2);
     to_load_order(v, tid, lds);
     uint4* __restrict__ out = reinterpret_cast<uint4*>(a.tspec + (size_t)blockIdx.x * FN);
 #pragma unroll
@@ -393,11 +402,9 @@ void tspec_kernel(TspecArgs a) {
     // microseconds) and the wave's share of the norm's SQUARE to the segment's accumulator (zeroed before the launch; slb_kernel
     // takes the root): staging both through the LDS, as spectra_kernel does once per stream, cost this kernel -- which runs every
     // step -- two barriers more and 0.6 ms of 1.0 at BASELINE configs[2].
-    if (!(a.dbg & 1)) a.tspec_low[(size_t)blockIdx.x * LROWE + sushi_fft::lslot_of_thread(tid)] = low;
-    if (!(a.dbg & 6)) {
-        const float w = wave_sum_shfl(rest2);
-        if ((tid & 63) == 0) atomicAdd(a.tnorm_rest + blockIdx.x, w);
-    }
+    a.tspec_low[(size_t)blockIdx.x * LROWE + sushi_fft::lslot_of_thread(tid)] = low;
+    const float w = wave_sum_shfl(rest2);
+    if ((tid & 63) == 0) atomicAdd(a.tnorm_rest + blockIdx.x, w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1359,6 +1366,8 @@ struct BoundArgs {
     unsigned char* audit_mark;        // [pairs of the sub-batch] bit 0 = excluded, transformed all the same (the audit of the exclusion); bit 1 = listed; bit 2 = excluded by the second look
     unsigned audit_seq;               // changes from run to run: which excluded pair of a search is audited
     int audit_every;                  // one search in this many is audited per run (0: none)
+    int worst_case;                   // 1: every rounding on the excluded side enters at its WORST CASE (slb_one; the default); 0: round 5's statistical model
+    float half_err;                   // what a packed-half transform output may be off by, in units of the largest pass-1 value (bound_low_kernel / bound_kernel)
     const int* list;                  // slb_list_kernel / bound_low_exact_kernel / survivor2_kernel: the pairs the first bound left ...
     const int* list_count;            // ... how many
     int* list2;                       // survivor2_kernel: the pairs the second look left ...
@@ -1425,7 +1434,7 @@ void bound_low_kernel(BoundArgs a) {
             sushi_fft::h2 v[sushi_fft::PER];
             unsigned in2;
             sushi_fft::fft_wave_half_front_low(yl, v, tw, mb, in2);
-            d2 += 0.0841f * __uint_as_float(wave_max_u32(in2));        // (0.29 x this group's largest pass-1 value)^2
+            d2 += a.half_err * a.half_err * __uint_as_float(wave_max_u32(in2));   // (half_err x this group's largest pass-1 value)^2
 #pragma unroll
             for (int r = 0; r < sushi_fft::PER; ++r) msum[r] = __builtin_amdgcn_fdot2(v[r], v[r], msum[r], false);
 #pragma unroll
@@ -1501,7 +1510,7 @@ void bound_kernel(BoundArgs a) {
         if (lane == 0) {
             const size_t pr = (size_t)(it >> 4);
             // the largest |A|: what the halves gave, their rounding (header of the packed-half passes), the 2^-10 undone
-            float bw = (sqrtf(__uint_as_float(wm)) * 1.002f + 0.29f * sqrtf(__uint_as_float(wi))) * 1024.0f;
+            float bw = (sqrtf(__uint_as_float(wm)) * 1.002f + a.half_err * sqrtf(__uint_as_float(wi))) * 1024.0f;
             if (wm >= 0x7f800000u || wi >= 0x7f800000u) bw = __builtin_inff();
             atomicAdd(a.acc + 2 * pr, bw);
             atomicMax(reinterpret_cast<unsigned*>(a.acc + 2 * pr + 1), __float_as_uint(qw));
@@ -1635,8 +1644,30 @@ __device__ __forceinline__ void slb_one(const BoundArgs& a, const int pr, const 
         // float32 rounding included in the factor), the FFT stage's error, the packed halves' modelled error
         const double tn = CC ? (tc.inv_tnorm_c > 0.f ? 1.0 / (double)tc.inv_tnorm_c : 0.0) : (double)tc.tnorm;
         // (an UPPER bound of the signed cross term: the band-split form's may be negative)
-        const double ymax = (double)B * (double)tc.inv_scale + fabs((double)B) * (double)tc.inv_scale * 2e-5 + 5.9604645e-8 * (double)FFT_KE * (CC ? fmax(zn, zn_c) : zn_c) * tn +
-                            (double)Y_KQ * sigma_y;
+        double ymax = (double)B * (double)tc.inv_scale + fabs((double)B) * (double)tc.inv_scale * 2e-5;
+        if (a.worst_case) {
+            // THE EXCLUDED SIDE IS A PROOF, NOT A MODEL.  B bounds the transform of the halves AS STORED; the exact
+            // cross term differs from that by what the stored halves differ from the exact spectra by, every term at its worst case
+            // with all of them in phase (triangle inequality over the bins, no independence assumed):
+            //   |y[r] - y_stored[r]| <= sum_f |Tt Z - stored product|(f)
+            //      <= (2 u_h + 2 e_F + g) sum_s sum_f |Tt_s(f)| |Z_s(f)|  +  (passes) u_h sum_f |Y(f)|       u_h = 2^-11: a half's rounding
+            //      <= c sum_s |Tt_s| |Z_s|   (Cauchy-Schwarz over ALL bins, band and rest alike)
+            //      =  c sum_s |t_s| |z_s|    (Parseval: segment s of the pattern, the 2 N centred samples block 6 I + s packs)
+            //      <= c |T| sqrt(sum_s |z_s|^2) <= c |T| sqrt(8) zn_c
+            // (every sample of the pair's span of n_seg + 6 blocks enters at most four block spectra as a first and four as a second
+            // half).  e_F = 1e-5 >= 14 (mu + g_4 (sqrt 2 + mu)): the float32 forward transforms' relative error in the 2-norm (Higham,
+            // Accuracy and Stability of Numerical Algorithms, Thm 24.2, log2 N = 14 radix-2 levels, twiddles good to 4 u);
+            // g <= 2e-5: mac_kernel's float32 sums.  The same terms cover what the NORMS of the stored rows outside the band differ
+            // from the exact rows' by, and what the stored pattern rows lack of conjugate symmetry.  The halves' subnormal floor
+            // (2^-25 absolute per stored value, N bins a row): of the pattern rows < 1.3e-9 sqrt(n_seg) |T| zn_c (inside c), of the block
+            // rows 3.3e-10 sqrt(n_seg) |T| sqrt(E7) (1 / the stream's scale <= 0.01105 sqrt(E7)), of Y itself N 2^-25 of its units.
+            const double c_wc = (double)(mac_passes + 2) * 4.8829e-4 * 1.001 + 4e-5;
+            const double zn_wc = CC ? fmax(zn, zn_c) : zn_c;
+            ymax += c_wc * 2.8284272 * tn * zn_wc
+                  + 3.3e-10 * sqrt((double)n_seg) * tn * sqrt(fmax(a.dst_stats[0], 0.0)) + 5e-4 * (double)tc.inv_scale;
+        } else {
+            ymax += 5.9604645e-8 * (double)FFT_KE * (CC ? fmax(zn, zn_c) : zn_c) * tn + (double)Y_KQ * sigma_y;
+        }
         float slb = -__builtin_inff();
         bool room = false;          // (prediction) the bound, with nothing but the norms outside the band in it, keeps 55 % of what a zero cross term would score
         if (CC) {
@@ -2351,6 +2382,7 @@ struct SushiHipBatch {
     int band_votes[2];                  // what the decision was taken from: pairs looked at, pairs whose bound leaves room
     unsigned run_seq;                   // runs so far: rotates which excluded pairs are audited
     int audit_every;                    // one search in this many has one excluded pair transformed as a check, per run
+    int bound_model;                    // SUSHI_HIP_BOUND_WORST_CASE (default) / _STATISTICAL: how the excluded side's roundings enter slb
     int last_band;                      // form of the exclusion the last run's last sub-batch used (-1: none)
     // AUTO learns from its own runs: a batch whose exclusion excluded next to nothing (searches without a match anywhere) runs
     // without it from then on, looking again every 64th run.  The last run's counts come back through 16 bytes of pinned host memory
@@ -2468,9 +2500,13 @@ int sushi_hip_batch_create(const SushiHipStream* dst, const SushiHipStream* src,
     b->packed_out = nullptr;
     b->host_stats = nullptr; b->stats_ready = nullptr; b->stats_pending = false; b->suspended = 0; b->suspended_at = 0; b->last_suspended = 0;
     b->band = -1; b->last_band = -1; b->band_decided_method = -1; b->band_votes[0] = b->band_votes[1] = 0; b->run_seq = 0; b->audit_every = 2;
+    b->bound_model = SUSHI_HIP_BOUND_WORST_CASE;
     {
-        const char* e = getenv("SUSHI_HIP_AUDIT_EVERY");      // (measurements: 0 = no excluded pair is audited)
+        // (measurements only, read once per batch: 0 = no excluded pair is audited; "statistical" = round 5's error model)
+        const char* e = getenv("SUSHI_HIP_AUDIT_EVERY");
         if (e && *e) { const int v = atoi(e); b->audit_every = v < 0 ? 0 : v; }
+        const char* m = getenv("SUSHI_HIP_BOUND_MODEL");
+        if (m && !strcmp(m, "statistical")) b->bound_model = SUSHI_HIP_BOUND_STATISTICAL;
     }
     b->mem = (char*)mem_dev; b->last_stream = nullptr; b->ran = false; b->uploaded = nullptr;
     int rc = make_descs(req_host, n, variant, b->descs, &b->n_tiles);
@@ -2547,6 +2583,12 @@ int sushi_hip_batch_set_exclusion(SushiHipBatch* b, int mode) {
     return SUSHI_HIP_OK;
 }
 
+int sushi_hip_batch_set_bound_model(SushiHipBatch* b, int model) {
+    if (!b || (model != SUSHI_HIP_BOUND_WORST_CASE && model != SUSHI_HIP_BOUND_STATISTICAL)) return SUSHI_HIP_EINVAL;
+    b->bound_model = model;
+    return SUSHI_HIP_OK;
+}
+
 int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, float* out_score_dev, void* hip_stream) try {
     if (!b || !out_idx_dev || !out_score_dev) return SUSHI_HIP_EINVAL;
     hipStream_t st = (hipStream_t)hip_stream;
@@ -2620,7 +2662,6 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         ta.tspec = tspec; ta.sub_first_pair = sbt.first_pair; ta.pairmap = pairmap; ta.tconst = tconst;
         ta.src_s1 = src->s1; ta.src_s2 = src->s2; ta.centre = r.centre; ta.dst_stats = dst->stats; ta.method = b->method;
         ta.tspec_low = tspec_low; ta.tnorm_rest = tnorm_rest;
-        { const char* e = getenv("SUSHI_HIP_TSPEC_DBG"); ta.dbg = e && *e ? atoi(e) : 0; }
         if (hipMemsetAsync(tnorm_rest, 0, (size_t)sbt.segs * sizeof(float), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
         if (src->dtype == SUSHI_HIP_F32) hipLaunchKernelGGL(tspec_kernel<float>, dim3((unsigned)sbt.segs), dim3(FT), 0, st, ta);
         else hipLaunchKernelGGL(tspec_kernel<uint8_t>, dim3((unsigned)sbt.segs), dim3(FT), 0, st, ta);
@@ -2644,6 +2685,15 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         ba.acc = (float*)(wsp + wl.acc);
         ba.sub_first_seg = sbt.first_seg; ba.tnorm_rest = tnorm_rest; ba.znorm_rest = dst->znorm_rest; ba.norm_stride = dst->norm_stride; ba.band_votes = scount + 2;
         ba.audit_mark = (unsigned char*)(wsp + wl.audit_mark); ba.audit_seq = run_seq; ba.audit_every = b->audit_every;
+        // What a packed-half transform output (bound_low_kernel / bound_kernel) may be off by, in units of the largest pass-1 value:
+        // every output is a sum of 64 pass-1 values through ROUNDING LEVELS of 2^-11 each -- a level at which the partial sums hold m
+        // terms each costs 2^-11 m per value and 64 / m values meet in an output: 2^-11 64 per level whatever m.  Worst path: pass 1's
+        // own result 1, its half-precision matrix (2^-12 sqrt 2 per entry, sum |inputs| <= 4 max |output| by Parseval) 2.8, pass 2's
+        // twiddle 2 + its radix-16 butterflies 1 + 1 + 2 + 3 (h_bfly_root32: q = 0 / 8 one rounding, 4 / 12 two, others three on the
+        // e - w o side), pass 3's twiddle 2 + radix 4: 1 + 1, four levels of half-precision twiddle constants at 2^-12 each = 2:
+        // 18.8 levels = 0.59.  (Round 5's 0.29 counted 9: about right for independent roundings, not a worst case.)
+        ba.worst_case = b->bound_model == SUSHI_HIP_BOUND_WORST_CASE ? 1 : 0;
+        ba.half_err = ba.worst_case ? 0.6f : 0.29f;
         auto launch_slb = [&](const BoundArgs& x) {
             if (ccm) hipLaunchKernelGGL(slb_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3((unsigned)((sbt.pairs + 3) / 4)), dim3(256), 0, st, x);
             else hipLaunchKernelGGL(slb_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3((unsigned)((sbt.pairs + 3) / 4)), dim3(256), 0, st, x);

@@ -333,6 +333,20 @@ class SearchBatch(object):
         _native.check(_native.lib().sushi_hip_batch_set_packed_output(self._handle, packed.data_ptr()), "sushi_hip_batch_set_packed_output")
         self._packed = packed           # kept alive with the batch
 
+    def set_method(self, method):
+        """Matching method of the following runs (sushi_hip_batch_set_method): 'sqdiff_normed' or 'ccoeff_normed'."""
+        if method not in _native.METHODS:
+            raise SushiError("method must be one of %s" % sorted(_native.METHODS))
+        _native.check(_native.lib().sushi_hip_batch_set_method(self._handle, _native.METHODS[method]), "sushi_hip_batch_set_method")
+        self.method = method
+
+    def set_bound_model(self, model):
+        """'worst_case' (default: the excluded side of the pair exclusion is a proof) or 'statistical' (round 5's model; A/B)."""
+        if model not in _native.BOUND_MODEL:
+            raise SushiError("bound model must be one of %s" % sorted(_native.BOUND_MODEL))
+        _native.check(_native.lib().sushi_hip_batch_set_bound_model(self._handle, _native.BOUND_MODEL[model]),
+                      "sushi_hip_batch_set_bound_model")
+
     def run(self, hip_stream=None):
         """One pass of the hot path over this batch (asynchronous)."""
         st = _raw_stream(self.dst.device) if hip_stream is None else hip_stream

@@ -108,14 +108,18 @@ class ShardedSearch(object):
 
     The gather's buffers are allocated once; a batch that can write its (index, score bits) records itself (SearchBatch.
     set_packed_output) does so from the second step on: a step is then the library's kernels, the one collective and one (equal
-    blocks) or two (unequal blocks) small kernels on the way out; at 375 events per rank a step is 3.5 ms of
-    kernels, and a dozen tiny launches around the collective would be a few per cent of it.
+    blocks) or two (unequal blocks) small kernels on the way out; at 375 events per rank (BASELINE configs[2] on 8 ranks) a step
+    is ~1.6 ms of kernels (bench.py --emulate-shards 8), and a dozen tiny launches around the collective would be several per cent of it.
+
+    `always_collective`: run the collective code path even when the group has ONE rank (tests: RCCL's all_gather_into_tensor on
+    device memory, exercised on a one-GPU box).
 
     CONTRACT of gather() / run(): the two returned tensors are CONTIGUOUS rows of one persistent buffer of this object --
     valid until the next gather(), which overwrites them in place.  Keep results across steps with .clone()."""
 
-    def __init__(self, n_total, make_batch, group=None, device=None, weights=None):
+    def __init__(self, n_total, make_batch, group=None, device=None, weights=None, always_collective=False):
         self.n_total = n_total
+        self.always_collective = bool(always_collective)
         self.group = group
         self.device = device
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -140,8 +144,10 @@ class ShardedSearch(object):
         return torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.float32, device=dev)
 
     def gather(self, idx, score):
-        """The one collective of the path: everyone's (idx, score) in global search order."""
-        if self.world == 1:
+        """The one collective of the path: everyone's (idx, score) in global search order -- of the tensors PASSED IN (this
+        rank's block, hi - lo entries).  When they are the batch's own output tensors and the batch leaves its records in the
+        gather buffer itself (from the second call on), no copy is made; any other tensors are packed by two small copies."""
+        if self.world == 1 and not self.always_collective:
             return idx, score
         pad = max(hi - lo for lo, hi in self._bounds)
         if self._packed is None or self._packed.device != idx.device:
@@ -162,7 +168,10 @@ class ShardedSearch(object):
                 self._packed[:n, 0].copy_(idx)
                 self._packed[:n, 1].copy_(score.view(torch.int32))
         n = idx.shape[0]
-        if not self._self_packed:
+        # (the records the batch wrote itself are only THESE results if the caller hands in the batch's own outputs)
+        own = self._self_packed and idx.data_ptr() == self.batch.out_idx.data_ptr() and \
+            score.data_ptr() == self.batch.out_score.data_ptr()
+        if not own:
             self._packed[:n, 0].copy_(idx)
             self._packed[:n, 1].copy_(score.view(torch.int32))
         dist.all_gather_into_tensor(self._full, self._packed, group=self.group)

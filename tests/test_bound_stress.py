@@ -1,6 +1,6 @@
 """The FFT path's ranking bound on material chosen to break the assumptions behind it -- the f32 transform
 error model and, since the products are kept as packed halves, the quantisation model: slowly drifting DC, amplitude steps over
-four orders of magnitude, sparse spikes, pure tones, quantised staircases; uint8 and float32 at several magnitudes.  Every search
+four orders of magnitude, sparse spikes, pure tones, quantised staircases, bursts of a tone at exactly Fs/8 (the edge of the low band) on block boundaries; uint8 and float32 at several magnitudes.  Every search
 must equal the oracle and no evaluated position -- candidate or audited non-candidate -- may be further from its f32 score
 than the pair's bound (a violation would show as `all_positions`).  tools/bound_hunt.py is the long version."""
 import os
@@ -13,13 +13,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("kind", ["drift", "steps", "spikes", "tones", "staircase", "noise"])
+@pytest.mark.parametrize("kind", ["drift", "steps", "spikes", "tones", "staircase", "noise", "fs8burst"])
 def test_bound_holds_on_adversarial_material(oracle, kind):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bound_hunt
     from sushi_amd.device import DeviceStream, SearchBatch
     from test_gpu_parity import _check_f32, _check_u8
-    rng = np.random.default_rng({"drift": 1, "steps": 2, "spikes": 3, "tones": 4, "staircase": 5, "noise": 6}[kind])
+    rng = np.random.default_rng({"drift": 1, "steps": 2, "spikes": 3, "tones": 4, "staircase": 5, "noise": 6, "fs8burst": 7}[kind])
     for u8, mag in ((True, 1.0), (False, 1.0), (False, 300.0), (False, 1e-3)):
         n = 180000
         x = bound_hunt.make(kind, n, rng)

@@ -75,3 +75,45 @@ def test_a_rank_without_searches_contributes_device_tensors():
     assert idx.is_cuda and score.is_cuda and idx.numel() == 0
     packed = pack_results(idx, score, 3)
     assert packed.is_cuda and packed.shape == (3, 2) and int(packed[0, 0]) == -1
+
+
+def test_the_rccl_collective_path_on_one_gpu():
+    """a one-GPU box can still load librccl, initialise the `nccl` backend and push DEVICE tensors through
+    ShardedSearch.gather's real collective code path (world size 1, the early-out switched off): all_gather_into_tensor on HBM,
+    the batch writing its (index, score bits) records into the gather buffer itself from the second step on, and -- ADVICE r5 --
+    foreign tensors handed to gather() are gathered as they are, not replaced by the batch's last results."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from sushi_amd.device import DeviceStream, SearchBatch
+        from sushi_amd.distributed import ShardedSearch
+        rng = np.random.default_rng(0)
+        dst = rng.random(200000, dtype=np.float32)
+        src = dst[20000:120000].copy()
+        n_total = 5
+        offs = [1000 + 9000 * k for k in range(n_total)]
+        lens = [5000 + 100 * k for k in range(n_total)]
+        d, s = DeviceStream(dst, device=dev), DeviceStream(src, device=dev)
+        sh = ShardedSearch(n_total, lambda lo, hi: SearchBatch(d, s, offs[lo:hi], lens[lo:hi], [0] * (hi - lo), [150000] * (hi - lo)),
+                           device=dev, always_collective=True)
+        want = [20000 + o for o in offs]
+        for step in range(3):                                  # step 0 packs by hand, steps 1.. let the library write the records
+            idx, score = sh.run()
+            torch.cuda.synchronize(dev)
+            assert idx.is_cuda and score.is_cuda and [int(x) for x in idx.cpu()] == want, step
+            assert float(score.max()) < 1e-5
+        assert sh._self_packed
+        # foreign tensors: gathered as passed in
+        fi = torch.arange(100, 100 + n_total, dtype=torch.int32, device=dev)
+        fs = torch.full((n_total,), 0.25, dtype=torch.float32, device=dev)
+        gi, gs = sh.gather(fi, fs)
+        torch.cuda.synchronize(dev)
+        assert [int(x) for x in gi.cpu()] == list(range(100, 100 + n_total)) and float(gs.min()) == float(gs.max()) == 0.25
+        idx, score = sh.run()                                  # ... and the batch's own results again afterwards
+        torch.cuda.synchronize(dev)
+        assert [int(x) for x in idx.cpu()] == want
+    finally:
+        dist.destroy_process_group()

@@ -25,7 +25,7 @@ def test_library_builds_and_exports_all_declared_symbols():
 def test_host_only_entry_points():
     L = _native.lib()
     C = ctypes
-    assert L.sushi_hip_abi_version() == _native.ABI_VERSION == 11
+    assert L.sushi_hip_abi_version() == _native.ABI_VERSION == 12
     assert L.sushi_hip_strerror(0) == b"ok" and b"invalid" in L.sushi_hip_strerror(-1)
     assert L.sushi_hip_centre(_native.U8) == 128.0 and L.sushi_hip_centre(_native.F32) == 0.5
     N, B = L.sushi_hip_fft_size(), L.sushi_hip_fft_block()

@@ -242,7 +242,7 @@ def _lb_bin_of(entry, j):
 
 
 def test_low_band_rows_and_row_norms_are_the_spectra_again():
-    """Behind the block spectra: the low band (bins f < N/8, f >= 7N/8) of every block once more, in the order the bound's
+    """Behind the block spectra: the low band (bins |f| < N/8) of every block once more, in the order the bound's
     transform loads it -- the very same halves --, and the norm of each block's stored halves OUTSIDE the band."""
     import torch
     from sushi_amd import _native
@@ -259,8 +259,13 @@ def test_low_band_rows_and_row_norms_are_the_spectra_again():
     assert low.shape[0] == full.shape[0] == 7
     bins = np.array([[_lb_bin_of(e, j) for j in range(4)] for e in range(N // 16)]).reshape(-1)
     assert sorted(bins.tolist()) == list(range(N // 8)) + list(range(7 * N // 8, N))
-    assert (low == full[:, slot[bins]]).all()
-    rest = np.setdiff1d(np.arange(N), bins)
+    # the band is kept mirror-symmetric (|f| < N/8 strictly): bin 7N/8, whose mirror N/8 lies outside, is ZERO in the low row and
+    # counted with the rest (the split of the rest into the two real blocks' parts needs a symmetric set of bins)
+    expect = full[:, slot[bins]].copy()
+    expect[:, bins == 7 * N // 8] = 0
+    assert (low == expect).all()
+    rest = np.setdiff1d(np.arange(N), bins[bins != 7 * N // 8])
+    assert sorted(((-rest) % N).tolist()) == sorted(rest.tolist())
     halves = d.spectra().cpu().numpy().astype(np.float64).reshape(-1, N, 2)
     Z = (halves[..., 0] + 1j * halves[..., 1])[:, slot]                          # natural bin order, as stored
     ref = np.sqrt((np.abs(Z[:, rest]) ** 2).sum(axis=1))
@@ -330,3 +335,88 @@ def test_nothing_to_exclude_dense_rows_then_auto_leaves_the_exclusion_out(oracle
         ok, osc, row = _oracle(oracle, dst, src, offs[k], lens[k], wst[k], npos[k])
         assert abs(float(runs[0][1].view(np.float32)[k]) - osc) <= 1e-4 * osc + 2.5e-7
         assert int(runs[0][0][k]) == ok or abs(float(row[int(runs[0][0][k])]) - osc) <= 2.5e-7
+
+
+def test_auto_across_a_method_switch_a_suspension_and_the_look_again(oracle):
+    """AUTO's learnt state: the form is decided per batch AND method, a run that excluded next to nothing
+    suspends the exclusion for the runs after it, every 64th run looks again -- and the method may change in between.  One batch
+    of searches without a match anywhere, large enough for AUTO to try, driven through all of it: every run's results are the same
+    bits per method, and the oracle's."""
+    import torch
+    from sushi_amd.device import DeviceStream, SearchBatch
+    n = 130 * PAIR
+    dst = _stream(n, 51)
+    src = _stream(60000, 52)
+    rng = np.random.default_rng(53)
+    offs, lens, wst, npos = [], [], [], []
+    for k in range(28):
+        m = int(rng.integers(12000, 40000))
+        offs.append(int(rng.integers(0, 60000 - m))); lens.append(m)
+        wst.append(int(rng.integers(0, 4 * PAIR))); npos.append(120 * PAIR)
+    b = SearchBatch(DeviceStream(dst), DeviceStream(src), offs, lens, wst, npos, path="fft", exclusion="auto")
+    assert b.fft_pairs > 3000 + 2 * len(offs)
+    ref = {}
+
+    def run(method):
+        if b.method != method:
+            b.set_method(method)
+        b.run()
+        torch.cuda.synchronize()
+        idx, score = b.results()
+        d = b.diagnostics()
+        assert d["slb_violations"] == 0 and d["all_positions"] == 0, d
+        got = (idx.copy(), score.copy().view(np.uint32))
+        if method in ref:
+            assert (got[0] == ref[method][0]).all() and (got[1] == ref[method][1]).all(), (method, d)
+        else:
+            ref[method] = got
+            for k in (0, 11, 27):
+                ok, osc, row = _oracle(oracle, dst, src, offs[k], lens[k], wst[k], npos[k], method)
+                assert abs(float(got[1].view(np.float32)[k]) - osc) <= 1e-4 * abs(osc) + 2.5e-7, (method, k)
+                assert int(got[0][k]) == ok or abs(float(row[int(got[0][k])]) - osc) <= 2.5e-7, (method, k)
+        return d
+    d = run("sqdiff_normed")                                   # run 0: the exclusion is tried (and the form decided for this method)
+    assert d["suspended"] == 0 and d["band"] in (0, 1)
+    d = run("sqdiff_normed")                                   # run 1: it excluded next to nothing -> left out
+    assert d["suspended"] == 1 and d["band"] == -1 and d["pairs_transformed"] == b.fft_pairs
+    d = run("ccoeff_normed")                                   # the method changes while suspended: still left out, other results
+    assert d["suspended"] == 1 and d["pairs_transformed"] == b.fft_pairs
+    seen_look = []
+    for r in range(3, 70):
+        d = run("ccoeff_normed" if r % 3 else "sqdiff_normed")
+        if not d["suspended"]:
+            seen_look.append((r, d["band"], d["band_votes"]))
+            assert d["band"] in (0, 1)                         # the look-again run went through the exclusion (form decided for ITS method)
+    # suspended at run 1 (the run that read run 0's counts): runs with (r - 1) % 64 == 63 look again
+    assert [r for r, _, _ in seen_look] == [64], seen_look
+    d = run("sqdiff_normed")
+    assert d["suspended"] == 1
+
+
+def test_worst_case_and_statistical_bounds_give_the_same_results(oracle):
+    """The excluded side's bound is a worst case by default (sushi_hip_batch_set_bound_model); round 5's statistical model is kept
+    for A/B.  Same results either way, the oracle's; the worst case can only leave MORE pairs to transform, and on audio-like
+    material it leaves hardly any more."""
+    from sushi_amd.device import SearchBatch
+    dst, src, offs, lens, wst, npos, planted = _audio_like_job()
+    out = {}
+    for model in ("worst_case", "statistical"):
+        for form in ("band", "whole"):
+            b = SearchBatch(dst.device_stream(), src.device_stream(), offs, lens, wst, npos, path="fft", exclusion=form)
+            b.set_bound_model(model)
+            b.run()
+            idx, score = b.results()
+            d = b.diagnostics()
+            assert d["slb_violations"] == 0 and d["all_positions"] == 0 and d["max_slb_ratio_excluded"] < 1.0, (model, form, d)
+            out[model, form] = (idx.copy(), score.copy().view(np.uint32), d["pairs_transformed"] - d["excluded_audited"], b.fft_pairs)
+    ref = out["worst_case", "band"]
+    for key, v in out.items():
+        assert (v[0] == ref[0]).all() and (v[1] == ref[1]).all(), key
+    assert all(abs(int(i) - p) <= 1 for i, p in zip(ref[0], planted))
+    for form in ("band", "whole"):
+        wc, st = out["worst_case", form][2], out["statistical", form][2]
+        assert st <= wc <= st + max(8, st // 2) and wc < out["worst_case", form][3] // 5, (form, wc, st)
+    d0 = dst.data[0]
+    for k in (0, 17, 39):
+        ok, osc, _ = _oracle(oracle, d0, src.data[0], offs[k], lens[k], wst[k], npos[k])
+        assert int(ref[0][k]) == ok and abs(float(ref[1].view(np.float32)[k]) - osc) <= 1e-4 * osc + 2.5e-7

@@ -14,7 +14,7 @@ from oracle import oracle as O  # noqa: E402
 from sushi_amd.device import DeviceStream, SearchBatch  # noqa: E402
 from tests.test_gpu_parity import _check_f32, _check_u8  # noqa: E402
 
-KINDS = ("drift", "steps", "spikes", "tones", "staircase", "noise")
+KINDS = ("drift", "steps", "spikes", "tones", "staircase", "noise", "fs8burst")
 
 
 def make(kind, n, rng):
@@ -31,6 +31,15 @@ def make(kind, n, rng):
         x[k] += rng.uniform(-0.45, 0.45, k.shape[0])
     elif kind == "tones":
         x = 0.5 + 0.2 * np.sin(2 * np.pi * t / rng.integers(20, 400)) + 0.1 * np.sin(2 * np.pi * t / rng.uniform(7, 90)) + 0.002 * base
+    elif kind == "fs8burst":
+        # energy concentrated at EXACTLY Fs/8 -- bin N/8 of a block spectrum, the edge of the low band, whose mirror bin
+        # 7N/8 sat inside the band until the band was made symmetric -- in bursts that start on block boundaries (4096 samples),
+        # over a quiet low-passed floor: what the split of the rest-of-spectrum bound into the two real blocks' parts must survive
+        x = 0.5 + 0.02 * base
+        for b0 in range(0, n - 4096, 4096 * int(rng.integers(2, 5))):
+            ln = int(rng.integers(1, 4)) * 4096
+            ph = rng.uniform(0, 2 * np.pi)
+            x[b0:b0 + ln] += rng.uniform(0.15, 0.4) * np.sin(2 * np.pi * t[b0:b0 + ln] / 8.0 + ph)
     elif kind == "staircase":
         x = 0.5 + np.round(base * 8) / 32.0
     else:
