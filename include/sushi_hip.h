@@ -51,6 +51,8 @@ extern "C" {
 #define SUSHI_HIP_ELAUNCH (-3)   /* the HIP runtime rejected a launch / copy / memset (see hipGetLastError) */
 #define SUSHI_HIP_ENOSPACE (-4)  /* buffer or workspace too small */
 #define SUSHI_HIP_ENODEV (-5)    /* no gfx950 device visible */
+#define SUSHI_HIP_ENOMEM (-6)    /* the host ran out of memory while a plan was built (std::bad_alloc caught at the boundary) */
+#define SUSHI_HIP_EINTERNAL (-7) /* any other C++ exception caught at the boundary: a bug, never a property of the input */
 
 /* sample types of WavStream.data (wav.py:109: 'uint8' or 'float32') */
 #define SUSHI_HIP_U8 0
@@ -232,7 +234,11 @@ SUSHI_HIP_API int sushi_hip_batch_set_bound_model(SushiHipBatch* batch, int mode
  * out_packed_dev (8-byte aligned, n records; NULL = off) -- the block a rank contributes to the one all-gather of the path, written
  * by the kernel that writes out_idx / out_score instead of by two copies afterwards. */
 SUSHI_HIP_API int sushi_hip_batch_set_packed_output(SushiHipBatch* batch, int32_t* out_packed_dev);
-/* One pass of the hot path over the batch (asynchronous):
+/* One pass of the hot path over the batch.  Asynchronous, with ONE exception: the first run of a batch (and the first after its
+ * method changed) that goes through the pair exclusion in AUTO or ALWAYS mode reads 8 bytes back to decide the exclusion's form and
+ * synchronises `hip_stream` once for that (not capturable in a hipGraph; BAND, WHOLE and NEVER never synchronise, nor does a
+ * batch too small for AUTO to use the exclusion -- a drop-in find_substream call).  Environment variables are read when a batch is
+ * created, never here.
  *   out_idx_dev[n]   = result.argmin(axis=1)[0]        (wav.py:186)
  *   out_score_dev[n] = result[0][min_idx], float32     (wav.py:188)
  * delta (FFT path; > 0, <= 1): floor of the score margin inside which positions are re-evaluated exactly -- every
@@ -251,6 +257,16 @@ SUSHI_HIP_API int sushi_hip_batch_diagnostics(SushiHipBatch* batch, SushiHipBatc
  * cross term -- sqrt(2) and bin 0 in it --, the low row's energy) -- for tests and tools that look at how sharp the exclusion is.  *n_pairs
  * in: the capacity of the arrays, out: how many pairs there are.  Synchronises. */
 SUSHI_HIP_API int sushi_hip_batch_pair_bounds(SushiHipBatch* batch, float* slb_host, float* acc_host, int64_t* n_pairs);
+/* FFT path, after a run, for tests and tools: where the LAST sub-batch's pattern spectra and products live in the batch's workspace
+ * (packed halves, 4 bytes per bin, bin f of a whole row at sushi_hip_fft_slot_of_bin(f), of a low row at
+ * sushi_hip_fft_low_slot_of_bin(f)): TSPEC [segments][N], Y [block pairs][N] -- whole rows exist only for the pairs that were
+ * transformed --, TSPEC_LOW [segments][N/4], Y_LOW [block pairs][N/4] (band-split form only).  Synchronises; the memory is the
+ * caller's own batch buffer, valid until the next run. */
+#define SUSHI_HIP_WS_TSPEC 0
+#define SUSHI_HIP_WS_Y 1
+#define SUSHI_HIP_WS_TSPEC_LOW 2
+#define SUSHI_HIP_WS_Y_LOW 3
+SUSHI_HIP_API int sushi_hip_batch_workspace_view(SushiHipBatch* batch, int which, void** ptr_dev, size_t* bytes);
 SUSHI_HIP_API void sushi_hip_batch_destroy(SushiHipBatch* batch);
 
 /* FFT path geometry of one request: block pairs (inverse transforms) and pattern segments (forward transforms). */

@@ -28,6 +28,7 @@ STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish", "bound")
 STAGE_KERNELS = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "mac_list_kernel+mac_rows_kernel+ifft_kernel", "refine": "refine_kernel",
                  "finish": "collect_kernel+exact_tiles_kernel+unpack_keys_kernel", "bound": "bound_low_kernel|bound_kernel"}
 EXCLUSION = {"auto": 0, "always": 1, "never": 2, "band": 3, "whole": 4}        # SUSHI_HIP_EXCLUDE_*
+WS_TSPEC, WS_Y, WS_TSPEC_LOW, WS_Y_LOW = range(4)                               # SUSHI_HIP_WS_*
 BOUND_MODEL = {"worst_case": 0, "statistical": 1}                              # SUSHI_HIP_BOUND_*
 # every kernel a stage's HIP-event span covers (profiles/pmc_traffic.json is keyed by kernel)
 STAGE_KERNEL_SETS = {"tspec": ("tspec_kernel",), "mac": ("mac_kernel", "mac_long_kernel"),
@@ -130,6 +131,8 @@ def lib():
     L.sushi_hip_batch_set_bound_model.argtypes = [vp, ci]
     L.sushi_hip_batch_pair_bounds.restype = ci
     L.sushi_hip_batch_pair_bounds.argtypes = [vp, vp, vp, ctypes.POINTER(i64)]
+    L.sushi_hip_batch_workspace_view.restype = ci
+    L.sushi_hip_batch_workspace_view.argtypes = [vp, ci, pvp, ctypes.POINTER(sz)]
     L.sushi_hip_batch_destroy.restype = None
     L.sushi_hip_batch_destroy.argtypes = [vp]
     L.sushi_hip_fft_layout.restype = ci

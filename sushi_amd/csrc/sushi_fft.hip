@@ -343,7 +343,7 @@ struct TspecArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(FT)
+__global__ __launch_bounds__(FT, 8)        // (64 VGPRs: two workgroups of sixteen waves per CU -- at 69 only one fits, 1.15 -> 1.6 ms)
 void tspec_kernel(TspecArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     const int tid = threadIdx.x;
@@ -390,21 +390,23 @@ void tspec_kernel(TspecArgs a) {
     }
     sushi_fft::fft_split<FFT_LOGN, -1>(v, tid, lds, tw);
     const float sc = t_scale / (float)FN;
-    float rest2;
-    const uint4 low = low_entry_and_rest(v, sc, tid, rest2);
+    // The low entry straight to its place (sixteen half-written lines per wave, all completed by this workgroup within
+    // microseconds) and the wave's share of the norm's SQUARE to the segment's accumulator (zeroed before the launch; slb_kernel
+    // takes the root): staging both through the LDS, as spectra_kernel does once per stream, cost this kernel -- which runs every
+    // step -- two barriers more and 0.6 ms of 1.0 at BASELINE configs[2].  Both leave BEFORE the hand-over: nothing of them stays live.
+    {
+        float rest2;
+        const uint4 low = low_entry_and_rest(v, sc, tid, rest2);
+        a.tspec_low[(size_t)blockIdx.x * LROWE + sushi_fft::lslot_of_thread(tid)] = low;
+        const float w = wave_sum_shfl(rest2);
+        if ((tid & 63) == 0) atomicAdd(a.tnorm_rest + blockIdx.x, w);
+    }
     to_load_order(v, tid, lds);
     uint4* __restrict__ out = reinterpret_cast<uint4*>(a.tspec + (size_t)blockIdx.x * FN);
 #pragma unroll
     for (int u = 0; u < sushi_fft::PER / 4; ++u)
         out[sushi_fft::wslot_uint4(tid, u)] = uint4{pack_h2(v[4 * u].x * sc, v[4 * u].y * sc), pack_h2(v[4 * u + 1].x * sc, v[4 * u + 1].y * sc),
                                                     pack_h2(v[4 * u + 2].x * sc, v[4 * u + 2].y * sc), pack_h2(v[4 * u + 3].x * sc, v[4 * u + 3].y * sc)};
-    // The low entry straight to its place (sixteen half-written lines per wave, all completed by this workgroup within
-    // microseconds) and the wave's share of the norm's SQUARE to the segment's accumulator (zeroed before the launch; slb_kernel
-    // takes the root): staging both through the LDS, as spectra_kernel does once per stream, cost this kernel -- which runs every
-    // step -- two barriers more and 0.6 ms of 1.0 at BASELINE configs[2].
-    a.tspec_low[(size_t)blockIdx.x * LROWE + sushi_fft::lslot_of_thread(tid)] = low;
-    const float w = wave_sum_shfl(rest2);
-    if ((tid & 63) == 0) atomicAdd(a.tnorm_rest + blockIdx.x, w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2547,7 +2549,7 @@ int sushi_hip_batch_create(const SushiHipStream* dst, const SushiHipStream* src,
     if (rc != SUSHI_HIP_OK) return rc;
     *out = guard.release();
     return SUSHI_HIP_OK;
-} catch (...) { return SUSHI_HIP_ENOSPACE; }        // std::bad_alloc etc.: nothing crosses the C boundary
+} catch (const std::bad_alloc&) { return SUSHI_HIP_ENOMEM; } catch (...) { return SUSHI_HIP_EINTERNAL; }     // nothing crosses the C boundary
 
 int sushi_hip_batch_info(const SushiHipBatch* b, SushiHipBatchInfo* info) {
     if (!b || !info) return SUSHI_HIP_EINVAL;
@@ -2916,7 +2918,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             b->stats_pending = true;
     }
     return rc;
-} catch (...) { return SUSHI_HIP_ENOSPACE; }        // std::bad_alloc etc.: nothing crosses the C boundary
+} catch (const std::bad_alloc&) { return SUSHI_HIP_ENOMEM; } catch (...) { return SUSHI_HIP_EINTERNAL; }     // nothing crosses the C boundary
 
 int sushi_hip_batch_diagnostics(SushiHipBatch* b, SushiHipBatchDiag* diag, float* ranking_err_host, int32_t* flagged_host) try {
     if (!b || !diag) return SUSHI_HIP_EINVAL;
@@ -2958,7 +2960,7 @@ int sushi_hip_batch_diagnostics(SushiHipBatch* b, SushiHipBatchDiag* diag, float
         }
     }
     return SUSHI_HIP_OK;
-} catch (...) { return SUSHI_HIP_ENOSPACE; }        // std::bad_alloc etc.: nothing crosses the C boundary
+} catch (const std::bad_alloc&) { return SUSHI_HIP_ENOMEM; } catch (...) { return SUSHI_HIP_EINTERNAL; }     // nothing crosses the C boundary
 
 int sushi_hip_batch_pair_bounds(SushiHipBatch* b, float* slb_host, float* acc_host, int64_t* n_pairs) try {
     if (!b || !n_pairs) return SUSHI_HIP_EINVAL;
@@ -2973,7 +2975,25 @@ int sushi_hip_batch_pair_bounds(SushiHipBatch* b, float* slb_host, float* acc_ho
     if (slb_host && hipMemcpy(slb_host, wsp + wl.slb, (size_t)sbt.pairs * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return SUSHI_HIP_ELAUNCH;
     if (acc_host && hipMemcpy(acc_host, wsp + wl.acc, (size_t)sbt.pairs * 2 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return SUSHI_HIP_ELAUNCH;
     return SUSHI_HIP_OK;
-} catch (...) { return SUSHI_HIP_ENOSPACE; }
+} catch (const std::bad_alloc&) { return SUSHI_HIP_ENOMEM; } catch (...) { return SUSHI_HIP_EINTERNAL; }
+
+int sushi_hip_batch_workspace_view(SushiHipBatch* b, int which, void** ptr_dev, size_t* bytes) {
+    if (!b || !ptr_dev || !bytes) return SUSHI_HIP_EINVAL;
+    *ptr_dev = nullptr; *bytes = 0;
+    if (!b->ran || b->path != SUSHI_HIP_PATH_FFT || b->plan.subs.empty()) return SUSHI_HIP_OK;
+    if (hipStreamSynchronize(b->last_stream) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+    const SubBatch& sbt = b->plan.subs.back();
+    const WsLayout wl = ws_layout(sbt.pairs, sbt.segs, sbt.b0 - sbt.a0);
+    char* wsp = b->mem + b->lay.ws;
+    switch (which) {
+        case SUSHI_HIP_WS_TSPEC: *ptr_dev = wsp + wl.tspec; *bytes = (size_t)sbt.segs * ROW_BYTES; break;
+        case SUSHI_HIP_WS_Y: *ptr_dev = wsp + wl.y; *bytes = (size_t)sbt.pairs * ROW_BYTES; break;
+        case SUSHI_HIP_WS_TSPEC_LOW: *ptr_dev = wsp + wl.tspec_low; *bytes = (size_t)sbt.segs * LROW_BYTES; break;
+        case SUSHI_HIP_WS_Y_LOW: *ptr_dev = wsp + wl.ylow; *bytes = (size_t)sbt.pairs * LROW_BYTES; break;
+        default: return SUSHI_HIP_EINVAL;
+    }
+    return SUSHI_HIP_OK;
+}
 
 int sushi_hip_profile_begin(void) {
     for (ProfCall& c : g_prof)
@@ -3007,6 +3027,6 @@ int sushi_hip_profile_end(float* stage_ms, int max_calls, int* n_calls) try {
     g_prof.clear();
     *n_calls = out;
     return rc;
-} catch (...) { return SUSHI_HIP_ENOSPACE; }        // std::bad_alloc etc.: nothing crosses the C boundary
+} catch (const std::bad_alloc&) { return SUSHI_HIP_ENOMEM; } catch (...) { return SUSHI_HIP_EINTERNAL; }     // nothing crosses the C boundary
 
 }  // extern "C"

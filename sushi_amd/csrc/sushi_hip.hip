@@ -1163,6 +1163,8 @@ const char* sushi_hip_strerror(int code) {
         case SUSHI_HIP_ELAUNCH: return "HIP launch failed";
         case SUSHI_HIP_ENOSPACE: return "buffer or workspace too small";
         case SUSHI_HIP_ENODEV: return "no gfx950 device";
+        case SUSHI_HIP_ENOMEM: return "out of host memory";
+        case SUSHI_HIP_EINTERNAL: return "internal error (a C++ exception was caught at the boundary)";
         default: return "unknown sushi_hip error";
     }
 }

@@ -390,6 +390,17 @@ class SearchBatch(object):
                       "sushi_hip_batch_pair_bounds")
         return slb[:n.value], acc[:n.value]
 
+    def workspace_view(self, which):
+        """FFT path, after run(): the last sub-batch's pattern spectra / products as a float16 CUDA tensor of (re, im) pairs
+        (sushi_hip_batch_workspace_view; which = _native.WS_*).  A view of this batch's own buffer: valid until the next run()."""
+        ptr, nbytes = ctypes.c_void_p(), ctypes.c_size_t(0)
+        _native.check(_native.lib().sushi_hip_batch_workspace_view(self._handle, int(which), ctypes.byref(ptr), ctypes.byref(nbytes)),
+                      "sushi_hip_batch_workspace_view")
+        if not ptr.value:
+            return None
+        off = ptr.value - self._mem.data_ptr()
+        return self._mem[off:off + nbytes.value].view(torch.float16)
+
     def ranking_errors(self):
         """FFT path: |f32 FFT score - exact score| at every search's result position in the last run()
         (0 for searches the tile kernel finished)."""
