@@ -106,6 +106,20 @@ __device__ __forceinline__ unsigned pack_h2(float re, float im) {
     const h2 q = {(_Float16)__builtin_amdgcn_fmed3f(re, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(im, -65504.f, 65504.f)};
     return __builtin_bit_cast(unsigned, q);
 }
+// sum of |re|^2 + |im|^2 over the four stored words (re | im << 16) of one 16-byte entry, added to `acc`.
+// The entry is cast to EIGHT halves as a whole and taken apart by sub-vectors: hipcc 7.2 compiles the obvious form --
+// `bit_cast<half2>(entry[j])` for j = 0 .. 3 in an unrolled loop -- to four reads of the entry's FIRST word (it narrows the 16-byte
+// load to a dword: `v_dot2c_f32_f16 v7, v2, v2` four times over; a ten-line reproducer is in tools/experiments/README.md).  The row
+// energies behind the error model were therefore four times every fourth bin: right on noise-like rows, a factor 10^4 short on
+// a row whose energy sits in one bin.  Found in round 6 with bursts of a tone (tests/test_bound_stress.py "fs8burst").
+__device__ __forceinline__ float add_abs2_entry(const sushi_fft::uint4v e, float acc) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const h8 v = __builtin_bit_cast(h8, e);
+    acc = __builtin_amdgcn_fdot2(v.s01, v.s01, acc, false);
+    acc = __builtin_amdgcn_fdot2(v.s23, v.s23, acc, false);
+    acc = __builtin_amdgcn_fdot2(v.s45, v.s45, acc, false);
+    return __builtin_amdgcn_fdot2(v.s67, v.s67, acc, false);
+}
 constexpr int ROW_BYTES = FN * 4;              // a stored spectrum: one 32-bit word per bin
 constexpr int ROWE = FN / sushi_mac::BINS;     // ... as 16-byte entries (four bins: what a lane of mac_kernel owns)
 constexpr float Y_KQ = 8.0f;                  // the quantisation term of a pair's bound, in standard deviations
@@ -544,12 +558,12 @@ __device__ __forceinline__ void mac_chunk(const MacArgs& a, const int c0, const 
 #pragma unroll
                 for (int k = 0; k < sushi_mac::BINS; ++k) { re[k] = v.re[k] * sy; im[k] = v.im[k] * sy; }   // to the scale of Y
                 if (ACCUM) {                                    // patterns beyond one pass: the row accumulates (in halves)
-                    const u4 prev = *dst;
+                    // (the entry as EIGHT halves, not `bit_cast<half2>(prev[k])`: hipcc 7.2 reads the first word four times -- add_abs2_entry)
+                    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                    static_assert(sushi_mac::BINS == 4, "an entry is four bins");
+                    const h8 pv = __builtin_bit_cast(h8, *dst);
 #pragma unroll
-                    for (int k = 0; k < sushi_mac::BINS; ++k) {
-                        const h2 p = __builtin_bit_cast(h2, prev[k]);
-                        re[k] += (float)p.x; im[k] += (float)p.y;
-                    }
+                    for (int k = 0; k < sushi_mac::BINS; ++k) { re[k] += (float)pv[2 * k]; im[k] += (float)pv[2 * k + 1]; }
                 }
                 u4 o;
 #pragma unroll
@@ -810,17 +824,12 @@ __device__ __forceinline__ float ccoeff_cd(float inv_sqrt_m) { return 28.0f + 51
 // workgroup does: the address needs the pair index only, and the search's descriptor and constants (two more dependent
 // loads) are not needed before the epilogue -- with two workgroups per CU every serial hop at a workgroup's start is CU time.
 __device__ __forceinline__ float load_y(sushi_fft::uint4v (&yl)[4], const uint2* __restrict__ yin, const int tid) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const sushi_fft::uint4v* __restrict__ yh = reinterpret_cast<const sushi_fft::uint4v*>(yin);
     float q2 = 0.f;                                              // energy of this thread's part of the row (quantisation model)
 #pragma unroll
     for (int u = 0; u < sushi_fft::PER / 4; ++u) {
         yl[u] = yh[sushi_fft::wslot_uint4(tid, u)];              // four bins: eight halves, as they go to the matrix pipe
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const h2 h = __builtin_bit_cast(h2, yl[u][j]);
-            q2 = __builtin_amdgcn_fdot2(h, h, q2, false);                  // |Y(f)|^2 straight from the two halves
-        }
+        q2 = add_abs2_entry(yl[u], q2);                          // |Y(f)|^2 straight from the halves
     }
     return q2;
 }
@@ -1417,12 +1426,7 @@ void bound_low_kernel(BoundArgs a) {
             typedef _Float16 h2 __attribute__((ext_vector_type(2)));
             float q = 0.f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const h2 h = __builtin_bit_cast(h2, yl[u][j]);
-                    q = __builtin_amdgcn_fdot2(h, h, q, false);
-                }
+            for (int u = 0; u < 4; ++u) q = add_abs2_entry(yl[u], q);
             q2 += lane < 32 ? q : 0.f;
             if (g == 0) {
                 // Bin 0 apart: a pattern that is not centred (TM_SQDIFF_NORMED) meets whatever a stretch of the stream sums to
@@ -1491,15 +1495,9 @@ void bound_kernel(BoundArgs a) {
         const int64_t nx = it + waves < n_items ? it + waves : it;       // (the last item re-requests itself: unconditional loads)
         load_item(nx, yn);
         __builtin_amdgcn_sched_barrier(0);      // (left to itself the scheduler sinks these loads to the end of the loop body: no prefetch at all)
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         float q2 = 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const h2 h = __builtin_bit_cast(h2, yl[u][j]);
-                q2 = __builtin_amdgcn_fdot2(h, h, q2, false);
-            }
+        for (int u = 0; u < 4; ++u) q2 = add_abs2_entry(yl[u], q2);
         // the three in-wave passes in packed halves (fft_core.hpp): 2^-10 A_n1[k2], good to two digits -- enough for a bound
         sushi_fft::h2 v[sushi_fft::PER];
         unsigned in2;

@@ -441,6 +441,12 @@ def test_fft_every_segment_count_class_and_chunked_patterns(oracle, dtype):
         res = oracle.match_template(dst[wst[k]:wst[k] + npos[k] + lens[k] - 1], src[offs[k]:offs[k] + lens[k]])[0]
         chk(res, idx[k], score[k])
     assert wst[14] + idx[14] == 300000 and wst[8] + idx[8] == 300000       # the planted copy, whole and in part
+    # ... and by the ranking stage itself, not by the exact fall-back: no search may have missed its error bound.  (Until round 6
+    # the accumulating passes of patterns beyond 30 segments added the row's FIRST word to all four bins of an entry -- a hipcc
+    # miscompile of `bit_cast<half2>(entry[k])`, sushi_fft.hip add_abs2_entry -- and the bound's violation sent those searches to
+    # exact evaluation at every position: right results, thousands of times the work.)
+    d = b.diagnostics()
+    assert d["all_positions"] == 0 and d["max_bound_ratio"] < 1.0 and d["max_bound_ratio_noncandidate"] < 1.0, d
     # one search per sub-batch: the same bits
     (idx2, score2), _ = _run_batch(dst, src, offs, lens, wst, npos, "fft", want_batch=True, workspace_bytes=1)
     assert (idx2 == idx).all() and (score2.view(np.uint32) == score.view(np.uint32)).all()

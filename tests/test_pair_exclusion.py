@@ -64,8 +64,10 @@ def test_almost_every_pair_is_excluded_and_the_results_are_the_oracles(oracle, m
     # one pair per search is transformed first; whatever else survives is a fraction of the rest
     assert b.fft_pairs >= 9 * len(offs)
     # (windows of eight pairs: the pair transformed first is already an eighth; the band-split form's bound is the looser of the two)
-    # (the worst-case bound -- the default since round 6 -- leaves a few more than round 5's statistical one did: 57 of 111 here)
-    most = b.fft_pairs * 5 // 8 if d["band"] == 1 else b.fft_pairs // 3
+    # (the worst-case bound -- the default since round 6 -- leaves a few more than round 5's statistical one did: 57 of 111 here;
+    # on this material -- a float32 stream that sits on a level of 0.5 with an rms of 0.09 around it -- the worst case's term is at its
+    # most visible: 45 of 111 in the whole-row form where the statistical model left 35)
+    most = b.fft_pairs * 5 // 8 if d["band"] == 1 else b.fft_pairs * 9 // 20
     assert len(offs) <= d["pairs_transformed"] - d["excluded_audited"] <= most, (d["pairs_transformed"], b.fft_pairs)
     for k in range(len(offs)):
         ok, osc, row = _oracle(oracle, dst, src, offs[k], lens[k], wst[k], npos[k], method)
