@@ -222,7 +222,7 @@ def kernel_source_digest():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "sushi_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".hpp")):
+        if name.endswith((".hip", ".hpp")) or (name.endswith(".inc") and not name.startswith("_gen_")):
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
@@ -277,6 +277,11 @@ def main():
     ap.add_argument("--snr", type=float, default=20.0,
                     help="signal-to-noise ratio (dB) of the source stream = planted copy of the destination + white noise; "
                          "20 = the BASELINE workload (SURVEY 8d)")
+    ap.add_argument("--source", choices=("noise", "encode", "dub"), default="noise",
+                    help="what the source stream is beside the planted offset: `noise` = the destination + white noise at --snr (the "
+                         "BASELINE workload); `encode` = another encode of it (gain 0.7, 4 kHz low-pass, requantised to 8 bits: "
+                         "synth.make_src_pcm_other_encode); `dub` = the same music bed under each stream's OWN speech on half of the "
+                         "time (synth.make_dub_pcm) -- what Sushi's real inputs look like")
     ap.add_argument("--unrelated", action="store_true",
                     help="the source stream is INDEPENDENT audio of the same kind (no match anywhere: nothing the pair "
                          "exclusion can use) -- the worst case of a data-dependent step; parity is then the oracle sample only")
@@ -353,8 +358,8 @@ def main():
         cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "sushi_bench_streams_%d_%d_%s" % (
             os.getuid(), os.getppid(), os.environ.get("MASTER_PORT", "0")))
         own_cache = True
-    tag = "c%d_%g_%d_%s_%g_%g_%g_%d" % (args.config, cfg["minutes"], rate, args.sample_type, args.offset, args.hard_frac,
-                                        args.snr, int(args.unrelated))
+    tag = "c%d_%g_%d_%s_%g_%g_%g_%d%s" % (args.config, cfg["minutes"], rate, args.sample_type, args.offset, args.hard_frac,
+                                          args.snr, int(args.unrelated), "" if args.source == "noise" else "_" + args.source)
     cpath = os.path.join(cache, tag + ".npz") if cache else None
     hard_spans = []
     if cpath and rank != 0 and world > 1:
@@ -374,13 +379,22 @@ def main():
         src = WavStream.from_prepared(z["src"], rate, int(z["sample_count"]), int(z["padding_size"]))
         hard_spans = [(str(k), float(a), float(b)) for k, a, b in zip(z["hard_kind"], z["hard_a"], z["hard_b"])]
     else:
-        if args.hard_frac > 0:
-            dst_pcm, hard_spans = synth.make_hard_dst_pcm(seconds, rate, seed=seed)
-        else:
+        if args.source != "noise" and (args.hard_frac > 0 or args.unrelated):
+            raise SystemExit("--source %s goes with neither --hard-frac nor --unrelated" % args.source)
+        base_pcm = None
+        if args.source == "dub":
+            dst_pcm, src_pcm, _ = synth.make_dub_pcm(seconds, int(round(args.offset * rate)), rate, seed=seed)
+        elif args.source == "encode":
             dst_pcm = synth.make_dst_pcm(seconds, rate, seed=seed)
-        # --unrelated: the source is a planted copy of ANOTHER stream of the same kind -- nothing of it is in the destination
-        base_pcm = synth.make_dst_pcm(seconds, rate, seed=seed + 7777) if args.unrelated else dst_pcm
-        src_pcm = synth.make_src_pcm(base_pcm, int(round(args.offset * rate)), snr_db=args.snr, seed=seed + 1)
+            src_pcm = synth.make_src_pcm_other_encode(dst_pcm, int(round(args.offset * rate)), rate, seed=seed + 1)
+        else:
+            if args.hard_frac > 0:
+                dst_pcm, hard_spans = synth.make_hard_dst_pcm(seconds, rate, seed=seed)
+            else:
+                dst_pcm = synth.make_dst_pcm(seconds, rate, seed=seed)
+            # --unrelated: the source is a planted copy of ANOTHER stream of the same kind -- nothing of it is in the destination
+            base_pcm = synth.make_dst_pcm(seconds, rate, seed=seed + 7777) if args.unrelated else dst_pcm
+            src_pcm = synth.make_src_pcm(base_pcm, int(round(args.offset * rate)), snr_db=args.snr, seed=seed + 1)
         dst = WavStream.from_samples(dst_pcm, rate, sample_rate=rate, sample_type=args.sample_type)
         src = WavStream.from_samples(src_pcm, rate, sample_rate=rate, sample_type=args.sample_type)
         del dst_pcm, src_pcm, base_pcm
@@ -501,12 +515,22 @@ def main():
     # oracle has to find the very same position.  Every rank holds the same gathered results and reaches the same
     # verdict by itself (the oracle runs in-process on the few events concerned), so all ranks leave together.
     planted_mask = ~hard_mask if not args.unrelated else np.zeros(n_total, bool)      # --unrelated: no planted answer at all
+    if args.source == "dub":
+        # an event under the dub's own speech has no planted answer either (the louder part of its pattern is not in the
+        # destination): the planted check is for the events that lie in the shared bed alone, the oracle sample covers both kinds
+        gate = synth.speech_gate(int(round(seconds * rate)), rate, seed + 11)
+        cg = np.concatenate(([0], np.cumsum(gate)))
+        for k, (s_, e_) in enumerate(events):
+            a_, b_ = int((s_ + args.offset) * rate), int((e_ + args.offset) * rate) + 1
+            a_, b_ = max(0, min(a_, gate.shape[0])), max(0, min(b_, gate.shape[0]))
+            if cg[b_] - cg[a_] > 0:
+                planted_mask[k] = False
     off_planted = [int(k) for k in np.nonzero((v_err > 1.0) & planted_mask)[0]]
     beyond_planted = {"events": len(off_planted), "confirmed_by_oracle": 0}
     if off_planted:
         worst = float(v_err[planted_mask].max())
         # (below 20 dB the true minimum wanders further from the planted position: the oracle alone decides then)
-        if len(off_planted) > 32 or (worst > 2.0 and args.snr >= 20.0):
+        if args.source != "dub" and (len(off_planted) > 32 or (worst > 2.0 and args.snr >= 20.0)):
             raise SystemExit("verification pass: planted offset not recovered on %d events (max error %.3f samples)"
                              % (len(off_planted), worst))
         _cpu_ctx.update(dst=dst.data[0], src=src.data[0], offs=offs, lens=lens, wst=wst, npos=npos, method=args.method)
@@ -679,6 +703,8 @@ def main():
                 wl_key += "/hard%g/off%g" % (args.hard_frac, args.offset)
             if args.snr != 20.0 or args.unrelated:
                 wl_key += "/snr%g%s" % (args.snr, "/unrelated" if args.unrelated else "")
+            if args.source != "noise":
+                wl_key += "/source-" + args.source
             if args.exclusion not in (None, "auto"):
                 wl_key += "/exclusion-" + args.exclusion
             digest = kernel_source_digest()
@@ -758,8 +784,11 @@ def main():
                        "work_per_gpu_over_mean": [round(float(work[a:b].sum() / (work.sum() / world)), 4)
                                                   for a, b in sharded.all_bounds()],
                        "window_s": cfg["window"], "stream_minutes": cfg["minutes"], "sample_rate": rate,
-                       "sample_type": args.sample_type, "hard_events": int(hard_mask.sum()),
-                       "source_snr_db": args.snr, "source_unrelated_to_destination": bool(args.unrelated),
+                       "sample_type": args.sample_type, "hard_events": int(hard_mask.sum()), "events_with_a_planted_answer": int(planted_mask.sum()),
+                       "source_snr_db": args.snr if args.source == "noise" else None, "source_unrelated_to_destination": bool(args.unrelated),
+                       "source_kind": {"noise": "destination advanced by the offset + white noise",
+                                       "encode": "another encode: gain 0.7, 4 kHz low-pass, requantised to 8 bits",
+                                       "dub": "shared music bed, each stream's own speech on half of the time"}[args.source],
                        "method": METHOD_TEXT[args.method],
                        "path": ("overlap-save FFT (f32) + exact float64 re-evaluation of the near-minimum positions"
                                 if args.path == "fft" else "direct exact-f32 MFMA sliding dot product"),

@@ -36,7 +36,8 @@ extern "C" {
                                      SushiHipBatchDiag.excluded_audited / .max_slb_ratio_excluded / .slb_violations / .band / .band_votes);
                                      11: SushiHipBatchDiag.second_look_audited (appended);
                                      12: sushi_hip_batch_set_bound_model (the excluded side of the pair exclusion is a worst-case bound by
-                                     default), the band is |f| < N/8 strictly (bin 7N/8 of a low row is zero and counted with the rest) */
+                                     default), the band is |f| < N/8 strictly (bin 7N/8 of a low row is zero and counted with the rest), sushi_hip_batch_reset,
+                                     sushi_hip_batch_workspace_view, SUSHI_HIP_ENOMEM / _EINTERNAL */
 
 #if defined(__GNUC__)
 #define SUSHI_HIP_API __attribute__((visibility("default")))
@@ -201,6 +202,12 @@ SUSHI_HIP_API int sushi_hip_batch_create(const SushiHipStream* dst, const SushiH
                                          const SushiHipRequest* req_host, int n, int path, int variant,
                                          size_t workspace_cap_bytes, void* mem_dev, size_t mem_bytes,
                                          void* hip_stream, SushiHipBatch** out);
+/* The same handle for OTHER requests (equally many, same streams, path and settings): descriptors, plan and schedule are redone
+ * in place and uploaded in one copy -- what a caller that issues one small batch after another (sushi.calculate_shifts: one
+ * find_substream call at a time, sushi.py:432,450-452) does instead of destroy + create.  ENOSPACE if the new requests need more
+ * than the memory the batch was created in (the handle is then unchanged and still runs its old requests); a run still in flight on
+ * another stream than `hip_stream` must have finished.  What the batch had learnt about its searches (exclusion form, suspension) is reset. */
+SUSHI_HIP_API int sushi_hip_batch_reset(SushiHipBatch* batch, const SushiHipRequest* req_host, int n, void* hip_stream);
 SUSHI_HIP_API int sushi_hip_batch_info(const SushiHipBatch* batch, SushiHipBatchInfo* info);
 /* Matching method of the following runs (default after create: SUSHI_HIP_METHOD_SQDIFF_NORMED).
  * SUSHI_HIP_METHOD_CCOEFF_NORMED: out_idx = first index of the MAXIMUM of cv2.matchTemplate(..., TM_CCOEFF_NORMED),

@@ -115,6 +115,8 @@ def lib():
     L.sushi_hip_batch_bytes.argtypes = [vp, ci, ci, ci, sz]
     L.sushi_hip_batch_create.restype = ci
     L.sushi_hip_batch_create.argtypes = [vp, vp, vp, ci, ci, ci, sz, vp, sz, vp, pvp]
+    L.sushi_hip_batch_reset.restype = ci
+    L.sushi_hip_batch_reset.argtypes = [vp, vp, ci, vp]
     L.sushi_hip_batch_info.restype = ci
     L.sushi_hip_batch_info.argtypes = [vp, ctypes.POINTER(BatchInfo)]
     L.sushi_hip_batch_set_method.restype = ci

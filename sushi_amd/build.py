@@ -28,6 +28,10 @@ UNITS = [
     # register shuffles (v_mov / accvgpr traffic); plain v_fma_f32 already issues at the f32 peak rate.
     ("sushi_fft", ["-fno-slp-vectorize"],
      [os.path.join(CSRC, "fft_core.hpp"), os.path.join(CSRC, "mac_core.hpp"), TWIDDLE_INC, os.path.join(CSRC, "_gen_dft16_f16.inc"),
+      # the translation unit's parts, by stage (included inside its anonymous namespace)
+      os.path.join(CSRC, "sushi_fft_store.inc"), os.path.join(CSRC, "sushi_fft_spectra.inc"), os.path.join(CSRC, "sushi_fft_mac.inc"),
+      os.path.join(CSRC, "sushi_fft_ifft.inc"), os.path.join(CSRC, "sushi_fft_bound.inc"), os.path.join(CSRC, "sushi_fft_collect.inc"),
+      os.path.join(CSRC, "sushi_fft_plan.inc"),
       os.path.join(CSRC, "_gen_dft16_f16_bound.inc"), os.path.join(CSRC, "_gen_dft16_f16_bound_low.inc")]),
 ]
 

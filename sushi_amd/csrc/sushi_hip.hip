@@ -25,6 +25,7 @@
 // gfx950 only: wave64, 4 SIMDs/CU, 160 KiB LDS/CU.  No CUDA compatibility paths.
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include <float.h>
 
@@ -1108,8 +1109,30 @@ int launch_direct(const StreamRefs& r, const SearchDesc* searches_dev, int n_sea
     return launch_unpack(keys_dev, n_search, method, out_idx_dev, out_score_dev, out_packed_dev, st);
 }
 
-int launch_refine(const RefineParams& p, hipStream_t st) {
-    hipLaunchKernelGGL(reset_sub_kernel, dim3(1), dim3(1), 0, st, p.sub_flagged, p.n_citems, p.counters);
+__global__ __launch_bounds__(256)
+void fill_ranges_kernel(FillArgs a) {
+    const unsigned stride = gridDim.x * 256u;
+    for (int r = 0; r < a.n; ++r) {
+        uint32_t* __restrict__ p = a.p[r];
+        const uint32_t v = a.value[r];
+        // (16-byte stores where the range allows: every range starts 256-byte aligned)
+        const unsigned quads = a.words[r] >> 2;
+        uint4* __restrict__ p4 = reinterpret_cast<uint4*>(p);
+        for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < quads; i += stride) p4[i] = uint4{v, v, v, v};
+        for (unsigned i = (quads << 2) + blockIdx.x * 256u + threadIdx.x; i < a.words[r]; i += stride) p[i] = v;
+    }
+}
+
+int launch_fill(const FillArgs& a, hipStream_t st) {
+    uint64_t most = 0;
+    for (int r = 0; r < a.n; ++r) most = a.words[r] > most ? a.words[r] : most;
+    const unsigned grid = (unsigned)std::min<uint64_t>(1024, std::max<uint64_t>(1, (most / 4 + 255) / 256));
+    hipLaunchKernelGGL(fill_ranges_kernel, dim3(grid), dim3(256), 0, st, a);
+    return launch_ok();
+}
+
+int launch_refine(const RefineParams& p, hipStream_t st, bool reset) {
+    if (reset) hipLaunchKernelGGL(reset_sub_kernel, dim3(1), dim3(1), 0, st, p.sub_flagged, p.n_citems, p.counters);
     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
     hipLaunchKernelGGL(refine_kernel, dim3(p.n_sub), dim3(REFINE_THREADS), 0, st, p);
     return launch_ok();

@@ -111,7 +111,15 @@ struct RefineParams {
     int method;                       // SUSHI_HIP_METHOD_*
     const int* viol;                  // [all searches] or NULL: 1 = a pair's lower bound was found above a real score (ifft_kernel's audit)
 };
-int launch_refine(const RefineParams& p, hipStream_t st);
+// `reset`: first clear the sub-batch's flag / tile / candidate counters (one tiny launch); false when launch_fill has done it
+int launch_refine(const RefineParams& p, hipStream_t st, bool reset = true);
+
+// Up to FILL_RANGES ranges of 32-bit words set to a value each, in ONE launch: what a run clears before its first kernel (result
+// keys, flags, counters, the candidate rows of a small batch) used to be half a dozen hipMemsetAsync calls -- a third of the
+// launches of a drop-in find_substream call, whose cost IS its launches.
+constexpr int FILL_RANGES = 6;
+struct FillArgs { uint32_t* p[FILL_RANGES]; uint32_t words[FILL_RANGES]; uint32_t value[FILL_RANGES]; int n; };
+int launch_fill(const FillArgs& a, hipStream_t st);
 
 struct TileParams {
     StreamRefs r;

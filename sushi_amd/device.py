@@ -194,6 +194,45 @@ def default_path():
     return p
 
 
+def _checked_requests(dst, src, tmpl_off, tmpl_len, win_start, n_pos):
+    """The SushiHipRequest array of a batch (include/sushi_hip.h), after the checks the reference leaves to NumPy and cv2."""
+    tmpl_off = np.asarray(tmpl_off, dtype=np.int64).reshape(-1)
+    tmpl_len = np.asarray(tmpl_len, dtype=np.int64).reshape(-1)
+    win_start = np.asarray(win_start, dtype=np.int64).reshape(-1)
+    n_pos = np.asarray(n_pos, dtype=np.int64).reshape(-1)
+    n = tmpl_off.shape[0]
+    if not (tmpl_len.shape[0] == win_start.shape[0] == n_pos.shape[0] == n) or n == 0:
+        raise SushiError("descriptor arrays must be non-empty and of equal length")
+    if n <= 4:
+        # (a drop-in call is a batch of one, a triple one of three: a dozen NumPy reductions over one element each were a
+        # tenth of such a call -- tools/call_breakdown.py; the same checks in the same order on plain ints)
+        o_, m_, w_, p_ = tmpl_off.tolist(), tmpl_len.tolist(), win_start.tolist(), n_pos.tolist()
+        empty = any(m < 1 for m in m_)
+        too_long = any(p < 1 for p in p_)
+        bad_src = any(o < 0 or o + m > src.n for o, m in zip(o_, m_))
+        bad_dst = any(w < 0 or w + p + m - 1 > dst.n for w, p, m in zip(w_, p_, m_))
+        too_large = any(p > 0x7fffffff - 65536 or m > 0x7fffffff - 65536 for p, m in zip(p_, m_))
+    else:
+        empty = bool((tmpl_len < 1).any())
+        too_long = bool((n_pos < 1).any())
+        bad_src = bool((tmpl_off < 0).any() or (tmpl_off + tmpl_len > src.n).any())
+        bad_dst = bool((win_start < 0).any() or (win_start + n_pos + tmpl_len - 1 > dst.n).any())
+        too_large = bool((n_pos > 0x7fffffff - 65536).any() or (tmpl_len > 0x7fffffff - 65536).any())
+    if empty:
+        raise SushiError("empty pattern")
+    if too_long:
+        raise SushiError("pattern is longer than the search window (cv2.error in the reference)")
+    if bad_src:
+        raise SushiError("pattern slice outside the source stream")
+    if bad_dst:
+        raise SushiError("search window outside the destination stream")
+    if too_large:
+        raise SushiError("search too large")
+    req = np.zeros(n, dtype=_native.REQUEST_DTYPE)
+    req["tmpl_off"], req["win_start"], req["tmpl_len"], req["n_pos"] = tmpl_off, win_start, tmpl_len, n_pos
+    return req
+
+
 class SearchBatch(object):
     """Requests of a batch of searches, resident in HBM, plus the output buffers.
 
@@ -215,7 +254,7 @@ class SearchBatch(object):
     """
 
     def __init__(self, dst, src, tmpl_off, tmpl_len, win_start, n_pos, variant=None, path=None,
-                 delta=DEFAULT_DELTA, workspace_bytes=None, method="sqdiff_normed", exclusion=None):
+                 delta=DEFAULT_DELTA, workspace_bytes=None, method="sqdiff_normed", exclusion=None, headroom=1.0):
         self._handle = None
         if method not in _native.METHODS:
             raise SushiError("method must be one of %s" % sorted(_native.METHODS))
@@ -225,45 +264,13 @@ class SearchBatch(object):
         if dst.dtype != src.dtype:
             raise SushiError("pattern and stream sample types differ (cv2.matchTemplate asserts equal types)")
         self.dst, self.src = dst, src
-        tmpl_off = np.asarray(tmpl_off, dtype=np.int64).reshape(-1)
-        tmpl_len = np.asarray(tmpl_len, dtype=np.int64).reshape(-1)
-        win_start = np.asarray(win_start, dtype=np.int64).reshape(-1)
-        n_pos = np.asarray(n_pos, dtype=np.int64).reshape(-1)
-        n = tmpl_off.shape[0]
-        if not (tmpl_len.shape[0] == win_start.shape[0] == n_pos.shape[0] == n) or n == 0:
-            raise SushiError("descriptor arrays must be non-empty and of equal length")
-        if n <= 4:
-            # (a drop-in call is a batch of one, a triple one of three: a dozen NumPy reductions over one element each were a
-            # tenth of such a call -- tools/call_breakdown.py; the same checks in the same order on plain ints)
-            o_, m_, w_, p_ = tmpl_off.tolist(), tmpl_len.tolist(), win_start.tolist(), n_pos.tolist()
-            empty = any(m < 1 for m in m_)
-            too_long = any(p < 1 for p in p_)
-            bad_src = any(o < 0 or o + m > src.n for o, m in zip(o_, m_))
-            bad_dst = any(w < 0 or w + p + m - 1 > dst.n for w, p, m in zip(w_, p_, m_))
-            too_large = any(p > 0x7fffffff - 65536 or m > 0x7fffffff - 65536 for p, m in zip(p_, m_))
-        else:
-            empty = bool((tmpl_len < 1).any())
-            too_long = bool((n_pos < 1).any())
-            bad_src = bool((tmpl_off < 0).any() or (tmpl_off + tmpl_len > src.n).any())
-            bad_dst = bool((win_start < 0).any() or (win_start + n_pos + tmpl_len - 1 > dst.n).any())
-            too_large = bool((n_pos > 0x7fffffff - 65536).any() or (tmpl_len > 0x7fffffff - 65536).any())
-        if empty:
-            raise SushiError("empty pattern")
-        if too_long:
-            raise SushiError("pattern is longer than the search window (cv2.error in the reference)")
-        if bad_src:
-            raise SushiError("pattern slice outside the source stream")
-        if bad_dst:
-            raise SushiError("search window outside the destination stream")
-        if too_large:
-            raise SushiError("search too large")
+        req = _checked_requests(dst, src, tmpl_off, tmpl_len, win_start, n_pos)
+        n = req.shape[0]
         self.n = n
         self.path = default_path() if path is None else path
         if self.path not in ("fft", "direct"):
             raise SushiError("path must be 'fft' or 'direct'")
         path_code = _native.PATH_FFT if self.path == "fft" else _native.PATH_DIRECT
-        req = np.zeros(n, dtype=_native.REQUEST_DTYPE)
-        req["tmpl_off"], req["win_start"], req["tmpl_len"], req["n_pos"] = tmpl_off, win_start, tmpl_len, n_pos
         self.requests = req
         if workspace_bytes is None:
             workspace_bytes = int(os.environ.get("SUSHI_HIP_FFT_WS_MB", DEFAULT_FFT_WORKSPACE >> 20)) << 20
@@ -273,6 +280,7 @@ class SearchBatch(object):
         need = int(L.sushi_hip_batch_bytes(req.ctypes.data, n, path_code, var, int(workspace_bytes)))
         if need == 0:
             raise SushiError("batch does not fit: too many blocks in one batch, or an unknown kernel variant")
+        need = int(need * max(1.0, float(headroom)) + 255) // 256 * 256        # (room for reset() to other, larger requests)
         dev = dst.device
         dst_handle = dst.searchable() if self.path == "fft" else dst.handle
         with torch.cuda.device(dev):
@@ -294,9 +302,19 @@ class SearchBatch(object):
             # (index, score bits) records as well, written by the library's last kernel: results() is then ONE copy to the
             # host instead of two -- a fifth of what a drop-in call waits for its answer (tools/call_breakdown.py)
             self._packed = None
-            self.set_packed_output(torch.empty((n, 2), dtype=torch.int32, device=dev))
+            self._host_rec = None
+            if n <= 4:
+                # a drop-in call's answer is a handful of bytes: the library's last kernel writes the records straight into pinned
+                # host memory (device-visible under unified addressing) -- results() is then a wait, not a copy
+                self._host_rec = torch.empty((n, 2), dtype=torch.int32, pin_memory=True)
+                _native.check(L.sushi_hip_batch_set_packed_output(h, self._host_rec.data_ptr()), "sushi_hip_batch_set_packed_output")
+            else:
+                self.set_packed_output(torch.empty((n, 2), dtype=torch.int32, device=dev))
+        self._read_info()
+
+    def _read_info(self):
         info = _native.BatchInfo()
-        _native.check(L.sushi_hip_batch_info(h, ctypes.byref(info)), "sushi_hip_batch_info")
+        _native.check(_native.lib().sushi_hip_batch_info(self._handle, ctypes.byref(info)), "sushi_hip_batch_info")
         self.variant = int(info.variant)
         self.sub_batches = int(info.sub_batches)
         self.n_tiles = int(info.direct_tiles)
@@ -319,10 +337,27 @@ class SearchBatch(object):
     def handle(self):
         return self._handle
 
+    def reset(self, tmpl_off, tmpl_len, win_start, n_pos):
+        """The same batch for OTHER requests (equally many; same streams, path, method, exclusion): sushi_hip_batch_reset -- plan and
+        descriptors redone in place, one upload, no allocation.  False if the new requests need more memory than this batch was
+        created with (the batch is unchanged then): the caller makes a new one."""
+        req = _checked_requests(self.dst, self.src, tmpl_off, tmpl_len, win_start, n_pos)
+        if req.shape[0] != self.n:
+            raise SushiError("reset: a batch keeps its number of searches")
+        with torch.cuda.device(self.dst.device):
+            rc = _native.lib().sushi_hip_batch_reset(self._handle, req.ctypes.data, self.n, _raw_stream(self.dst.device))
+        if rc == -4:                                              # SUSHI_HIP_ENOSPACE
+            return False
+        _native.check(rc, "sushi_hip_batch_reset")
+        self.requests = req
+        self._read_info()
+        return True
+
     def set_packed_output(self, packed):
         """Multi-GPU callers: every following run() also leaves its results as (index, score bits) int32 pairs in the first n rows
         of `packed` (a contiguous int32 CUDA tensor [>= n, 2]) -- a rank's block of the all-gather, written by the library's last
         kernel instead of by two copies afterwards (sushi_amd.distributed.ShardedSearch).  None turns it off."""
+        self._host_rec = None
         if packed is None:
             _native.check(_native.lib().sushi_hip_batch_set_packed_output(self._handle, None), "sushi_hip_batch_set_packed_output")
             self._packed = None
@@ -357,6 +392,10 @@ class SearchBatch(object):
 
     def results(self):
         """(idx int32 ndarray, score float32 ndarray) -- synchronises."""
+        if self._host_rec is not None:
+            torch.cuda.current_stream(self.dst.device).synchronize()
+            rec = self._host_rec.numpy()
+            return rec[:, 0].copy(), rec[:, 1].copy().view(np.float32)
         if self._packed is not None:
             rec = self._packed[:self.n].cpu().numpy()
             return np.ascontiguousarray(rec[:, 0]), np.ascontiguousarray(rec[:, 1]).view(np.float32)

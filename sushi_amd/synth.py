@@ -104,6 +104,63 @@ def make_src_pcm(dst_pcm, offsets_samples, snr_db=20.0, seed=1):
     return np.clip(np.round(src), -32768, 32767).astype(np.int16)
 
 
+def _shifted(dst_pcm, off):
+    """float64 copy of dst advanced by `off` samples (zeros where that leaves the stream)."""
+    n = dst_pcm.shape[0]
+    idx = np.arange(n) + int(off)
+    valid = (idx >= 0) & (idx < n)
+    out = np.zeros(n)
+    out[valid] = dst_pcm[idx[valid]]
+    return out
+
+
+def make_src_pcm_other_encode(dst_pcm, offset_samples, rate=12000, gain=0.7, cutoff_hz=4000.0, bits=8, seed=1):
+    """What Sushi's source usually IS: another encode of the same programme -- here the destination advanced by the offset, at
+    another level (`gain`), band-limited (a 63-tap windowed-sinc low-pass at `cutoff_hz`) and requantised to `bits` bits (the
+    codec's noise stands in as quantisation noise: signal-dependent, not white, 6 dB per bit under full scale)."""
+    x = _shifted(dst_pcm, offset_samples) * gain
+    taps = 63
+    k = np.arange(taps) - (taps - 1) / 2.0
+    fc = cutoff_hz / rate
+    h = 2.0 * fc * np.sinc(2.0 * fc * k) * np.hamming(taps)
+    h /= h.sum()
+    x = np.convolve(x, h, mode="same")
+    step = float(1 << (16 - bits))
+    x = np.round(x / step) * step
+    return np.clip(np.round(x), -32768, 32767).astype(np.int16)
+
+
+def speech_gate(n, rate, seed, on_frac=0.5):
+    """bool[n]: alternating stretches of 5-15 s, `on_frac` of the time on -- where a dub's own speech sits."""
+    rng = np.random.default_rng(seed)
+    gate = np.zeros(n, bool)
+    t, on = 0, bool(rng.integers(0, 2))
+    while t < n:
+        ln = int(rng.uniform(5.0, 15.0) * rate * (2.0 * on_frac if on else 2.0 * (1.0 - on_frac)))
+        if on:
+            gate[t:t + ln] = True
+        t += ln
+        on = not on
+    return gate
+
+
+def make_dub_pcm(seconds, offset_samples, rate=12000, seed=0, bed_level=0.5, speech_level=0.8):
+    """A dub: both streams share the music-and-effects bed (the source's advanced by the offset, 30 dB of white noise on it); each
+    has its OWN speech on the same stretches (half of the time, speech_gate) -- unrelated audio, louder than the bed, exactly where
+    subtitles are.  Returns (dst int16, src int16, gate of the DESTINATION bool[n])."""
+    n = int(round(seconds * rate))
+    bed = make_dst_pcm(seconds, rate, seed=seed).astype(np.float64) * bed_level
+    gate = speech_gate(n, rate, seed + 11)
+    sp_dst = make_dst_pcm(seconds, rate, seed=seed + 12).astype(np.float64) * speech_level * gate
+    sp_src = make_dst_pcm(seconds, rate, seed=seed + 13).astype(np.float64) * speech_level * gate
+    dst = bed + sp_dst
+    rng = np.random.default_rng(seed + 14)
+    src = _shifted(bed, offset_samples) + _shifted(sp_src, offset_samples) + \
+        rng.standard_normal(n) * math.sqrt(float(np.mean(bed ** 2)) / 1000.0)
+    to16 = lambda v: np.clip(np.round(v), -32768, 32767).astype(np.int16)
+    return to16(dst), to16(src), gate
+
+
 def make_events(n_events, duration_s, max_abs_offset_s, seed=2, min_len=1.0, max_len=5.0):
     """Sorted event spans (start, end) in seconds: starts uniform in [15, dur-20-max|off|],
     durations U[min_len, max_len]."""

@@ -375,7 +375,22 @@ class WavStream(object):
             start_times.append(st)
             win_start.append(lo)
             n_pos.append(p)
-        batch = SearchBatch(dst_dev, src_dev, offs, lens, win_start, n_pos, method=method)
+        # A drop-in call is a batch of one (a triple of three): its cost is host work and launches, not arithmetic.  Such batches
+        # are kept per (source stream, size, method) and RE-PLANNED in place for the next call (sushi_hip_batch_reset: no
+        # allocation, one upload) instead of being built and torn down every time.
+        batch = None
+        pooled = n <= 4 and len(owners) == 1 and all(l is not None for l in located)
+        if pooled:
+            pool = self.__dict__.setdefault("_small_batches", {})
+            from .device import default_path
+            key = (id(src_dev), n, method, default_path(), os.environ.get("SUSHI_HIP_EXCLUSION"))   # (what a new batch would read from the environment)
+            batch = pool.get(key)
+            if batch is not None and (batch.dst is not dst_dev or batch.src is not src_dev or not batch.reset(offs, lens, win_start, n_pos)):
+                batch = None
+        if batch is None:
+            batch = SearchBatch(dst_dev, src_dev, offs, lens, win_start, n_pos, method=method, headroom=4.0 if pooled else 1.0)
+            if pooled:
+                pool[key] = batch
         batch.run()
         idx, score = batch.results()
         times = [st + (int(k) / float(self.sample_rate)) for st, k in zip(start_times, idx)]

@@ -5,6 +5,7 @@ import os
 import subprocess
 
 import numpy as np
+import pytest
 
 from sushi_amd import _native, build
 
@@ -105,3 +106,49 @@ def test_struct_layouts_match_header(tmp_path):
     d = _native.REQUEST_DTYPE
     assert vals == [d.itemsize, d.fields["tmpl_off"][1], d.fields["win_start"][1], d.fields["tmpl_len"][1],
                     d.fields["n_pos"][1], ctypes.sizeof(_native.BatchInfo), ctypes.sizeof(_native.BatchDiag)]
+
+
+@pytest.mark.gpu
+def test_batch_reset_replans_in_place_and_the_drop_in_call_reuses_its_batch(oracle):
+    """sushi_hip_batch_reset: the same handle for other requests -- results are those of a fresh batch; requests that need more
+    memory than the batch was created with are refused (ENOSPACE, the batch unchanged); WavStream.find_substream keeps one small
+    batch per (source, size, method) and re-plans it call after call."""
+    import numpy as np
+    from sushi_amd import synth
+    from sushi_amd.device import SearchBatch
+    from sushi_amd.wav import WavStream
+    rate = 12000
+    dst_pcm = synth.make_dst_pcm(120, rate, seed=11)
+    src_pcm = synth.make_src_pcm(dst_pcm, int(2.5 * rate), seed=12)
+    dst = WavStream.from_samples(dst_pcm, rate, sample_type="float32")
+    src = WavStream.from_samples(src_pcm, rate, sample_type="float32")
+    D, S = dst.device_stream(), src.device_stream()
+    reqs = [([200000], [30000], [150000], [200000]), ([400000], [9000], [380000], [120000]), ([600000], [48000], [500000], [300001])]
+    b = SearchBatch(D, S, *reqs[0], path="fft", headroom=4.0)
+    b.run()
+    got = [tuple(x.copy() for x in b.results())]
+    for r in reqs[1:]:
+        assert b.reset(*r)
+        b.run()
+        got.append(tuple(x.copy() for x in b.results()))
+    for r, (gi, gs) in zip(reqs, got):
+        f = SearchBatch(D, S, *r, path="fft")
+        f.run()
+        fi, fs = f.results()
+        assert (fi == gi).all() and (fs.view(np.uint32) == gs.view(np.uint32)).all()
+        assert int(gi[0]) + r[2][0] == r[0][0] + int(2.5 * rate)                    # the planted offset
+    # far larger than what the batch was created with: refused, and the batch still answers its last requests
+    assert not b.reset([100000], [60000], [0], [1200000])
+    b.run()
+    gi, gs = b.results()
+    assert (gi == got[-1][0]).all() and (gs.view(np.uint32) == got[-1][1].view(np.uint32)).all()
+    with pytest.raises(Exception):
+        b.reset([1, 2], [10, 10], [0, 0], [100, 100])                              # a batch keeps its number of searches
+    # the drop-in call: one pooled batch per (source stream, size, method), the reference's answers
+    odst = oracle.OracleWavStream(dst.data, dst.sample_rate, dst.sample_count, dst.padding_size)
+    for s, e, w in ((10.0, 12.5, 8.0), (40.0, 41.0, 20.0), (70.0, 74.0, 1.5), (20.0, 23.0, 30.0)):
+        p = src.get_substream(s, e)
+        d, t = dst.find_substream(p, s + 2.5, w)
+        rd, rt = odst.find_substream(p, s + 2.5, w)
+        assert abs(t - rt) <= 1e-12 and abs(float(d) - float(rd)) <= 1e-4 * float(rd) + 2.5e-7
+    assert len(dst._small_batches) == 1

@@ -25,7 +25,7 @@ rate, seconds, n_total = cfg["rate"], cfg["minutes"] * 60.0, cfg["events"]
 OFFSET = 7.25                                              # bench.py's default planted offset
 seed = 20260924 + args.config
 cache = os.environ["SUSHI_BENCH_CACHE"]
-z = np.load(os.path.join(cache, "c%d_%g_%d_float32_%g_0.npz" % (args.config, cfg["minutes"], rate, OFFSET)), allow_pickle=True)
+z = np.load(os.path.join(cache, "c%d_%g_%d_float32_%g_0_20_0.npz" % (args.config, cfg["minutes"], rate, OFFSET)), allow_pickle=False)
 dst = WavStream.from_prepared(z["dst"], rate, int(z["sample_count"]), int(z["padding_size"]))
 src = WavStream.from_prepared(z["src"], rate, int(z["sample_count"]), int(z["padding_size"]))
 events = synth.make_events(n_total, seconds, cfg["window"] + OFFSET, seed=seed + 2)
