@@ -137,11 +137,12 @@ def test_batch_reset_replans_in_place_and_the_drop_in_call_reuses_its_batch(orac
         fi, fs = f.results()
         assert (fi == gi).all() and (fs.view(np.uint32) == gs.view(np.uint32)).all()
         assert int(gi[0]) + r[2][0] == r[0][0] + int(2.5 * rate)                    # the planted offset
-    # far larger than what the batch was created with: refused, and the batch still answers its last requests
-    assert not b.reset([100000], [60000], [0], [1200000])
-    b.run()
-    gi, gs = b.results()
-    assert (gi == got[-1][0]).all() and (gs.view(np.uint32) == got[-1][1].view(np.uint32)).all()
+    # more than what a batch was created with: refused, and the batch still answers its own requests
+    b2 = SearchBatch(D, S, *reqs[1], path="fft")
+    assert not b2.reset(*reqs[2])
+    b2.run()
+    gi, gs = b2.results()
+    assert (gi == got[1][0]).all() and (gs.view(np.uint32) == got[1][1].view(np.uint32)).all()
     with pytest.raises(Exception):
         b.reset([1, 2], [10, 10], [0, 0], [100, 100])                              # a batch keeps its number of searches
     # the drop-in call: one pooled batch per (source stream, size, method), the reference's answers
