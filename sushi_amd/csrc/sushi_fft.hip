@@ -389,7 +389,8 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         const unsigned long long left = b->host_stats[0] - b->host_stats[1];
         b->last_transformed = b->host_stats[0];
         if (b->exclusion == SUSHI_HIP_EXCLUDE_AUTO) {
-            if ((double)left > 0.5 * (double)b->plan.pairs) { if (!b->suspended) b->suspended_at = run_seq; b->suspended = 1; }
+            // (three quarters: a batch HALF of whose searches find nothing -- a dub -- still gains from the exclusion on the other half)
+            if ((double)left > 0.75 * (double)b->plan.pairs) { if (!b->suspended) b->suspended_at = run_seq; b->suspended = 1; }
             else b->suspended = 0;
         }
     }
@@ -492,8 +493,9 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
 
         // the multiply-accumulate over ALL pairs: of the low rows (band-split form) or of whole rows; `enable`: a device flag that
         // may call the launch off (the whole-row launch queued behind the survivors' list, below)
-        auto launch_mac = [&](const bool low, const int* enable) {
+        auto launch_mac = [&](const bool low, const int* enable, const int* dense_search) {
             MacArgs ma;
+            ma.dense_search = dense_search;
             ma.spec_blocks = dst->blocks;
             ma.searches = searches_dev + sbt.a0; ma.tconst = tconst; ma.sub_first_seg = sbt.first_seg;
             ma.sub_first_pair = sbt.first_pair;
@@ -520,7 +522,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             return SUSHI_HIP_OK;
         };
         t0 = prof_begin(pc, st);
-        if (launch_mac(band != 0, nullptr) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+        if (launch_mac(band != 0, nullptr, nullptr) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
         prof_end(pc, t0, SUSHI_HIP_STAGE_MAC, st);
 
         t0 = prof_begin(pc, st);
@@ -548,9 +550,9 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             return launch_ok();
         };
         // the whole rows of LISTED pairs (band-split form: nothing but the low band exists until a pair is to be transformed)
-        auto launch_mac_list = [&](const int* list, const int* count, int n_list, const int* disable, int long_only) {
+        auto launch_mac_list = [&](const int* list, const int* count, int n_list, const int* dense_search, int long_only) {
             MacListArgs la;
-            la.disable = disable; la.long_only = long_only;
+            la.dense_search = dense_search; la.long_only = long_only;
             la.spec = (const uint4*)dst->spec; la.spec_blocks = dst->blocks; la.tspec = (const uint4*)tspec; la.y = y;
             la.searches = searches_dev + sbt.a0; la.tconst = tconst; la.pairmap = pairmap; la.list = list; la.count = count;
             la.n_list = n_list; la.sub_first_seg = sbt.first_seg; la.sub_first_pair = sbt.first_pair;
@@ -568,7 +570,8 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             // (header of bound_kernel)
             ba.band = band;
             ba.y = band ? (const uint2*)ylow : (const uint2*)y;
-            if (hipMemsetAsync(ba.acc, 0, (size_t)sbt.pairs * 2 * sizeof(float), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+            // (bound_kernel adds to the pairs' accumulators; bound_low_kernel -- a wave per pair -- stores them)
+            if (!band && hipMemsetAsync(ba.acc, 0, (size_t)sbt.pairs * 2 * sizeof(float), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
             {
                 // persistent waves: four workgroups of four per CU (the kernel's register budget), fewer for a small batch
                 const int per_pair = band ? 1 : 16;                  // bound_low_kernel: a wave per pair
@@ -596,7 +599,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
                 // the second look at what the bound left (header of bound_low_exact_kernel): sharper bound, shorter list
                 ba.list = ba.slist; ba.list_count = ba.scount;
                 ba.list2 = (int*)(wsp + wl.slist2); ba.list2_count = scount + 5;
-                if (hipMemsetAsync(scount + 5, 0, sizeof(int), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+                if (!one_sub && hipMemsetAsync(scount + 4, 0, 2 * sizeof(int), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;   // (one sub-batch: cleared by the run's first launch)
                 hipLaunchKernelGGL(bound_low_exact_kernel, dim3(256 * 4), dim3(BLE_T), 0, st, ba);
                 if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
                 if (ccm) hipLaunchKernelGGL(slb_list_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3(256 * 2), dim3(256), 0, st, ba);
@@ -605,23 +608,26 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
                 hipLaunchKernelGGL(survivor2_kernel, dim3(256), dim3(256), 0, st, ba);
                 if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
                 final_list = ba.list2; final_count = ba.list2_count;
-                // whole rows of what is left: pair by pair while few are (the usual case), by the dense multiply-accumulate over all
-                // pairs when the bound excluded little (searches without a match: nothing can be excluded) -- decided on the device
-                int* dense = scount + 4;
-                hipLaunchKernelGGL(dense_mode_kernel, dim3(1), dim3(1), 0, st, final_count, (int)sbt.pairs, dense);
+                // whole rows of what is left: pair by pair for the searches that left few (the usual case), by the dense
+                // multiply-accumulate for the items of searches the bound could exclude little of (no match anywhere) -- decided per
+                // item of eight searches, on the device (dense_select_kernel)
+                int* any_dense = scount + 4;                         // (zero since the run's first launch)
+                int* dense = (int*)(wsp + wl.dense_search);
+                hipLaunchKernelGGL(dense_select_kernel, dim3((unsigned)(sbt.item_count[0] + sbt.item_count[1])), dim3(64), 0, st, ba,
+                                   items + (size_t)sbt.item_first[0] * (1 + MAC_SPW), dense, any_dense);
                 if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
                 {
                     MacRowsArgs ra;
                     ra.spec = (const uint4*)dst->spec; ra.spec_blocks = dst->blocks; ra.tspec = (const uint4*)tspec; ra.y = y;
                     ra.searches = searches_dev + sbt.a0; ra.tconst = tconst; ra.mark = ba.audit_mark; ra.n_sub = n_sub;
-                    ra.sub_first_seg = sbt.first_seg; ra.sub_first_pair = sbt.first_pair; ra.disable = dense;
+                    ra.sub_first_seg = sbt.first_seg; ra.sub_first_pair = sbt.first_pair; ra.dense_search = dense;
                     const int64_t want = (int64_t)n_sub * MACL_PARTS;
                     if (sbt.item_count[0] > 0) hipLaunchKernelGGL(mac_rows_kernel<0>, dim3((unsigned)std::min<int64_t>(want, 256 * 32)), dim3(MACL_THREADS), 0, st, ra);
                     if (sbt.item_count[1] > 0) hipLaunchKernelGGL(mac_rows_kernel<1>, dim3((unsigned)std::min<int64_t>(want, 256 * 16)), dim3(MACL_THREADS), 0, st, ra);
                     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
                 }
                 if (sbt.long_patterns && launch_mac_list(final_list, final_count, (int)sbt.pairs, dense, 1) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-                if (launch_mac(false, dense) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+                if (launch_mac(false, any_dense, dense) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             }
             ip.order = final_list; ip.count = final_count; ip.audit_mark = ba.audit_mark;
             // One workgroup per list slot up to what the list usually holds (an eighth of the pairs: empty slots there cost a
