@@ -277,11 +277,13 @@ def main():
     ap.add_argument("--snr", type=float, default=20.0,
                     help="signal-to-noise ratio (dB) of the source stream = planted copy of the destination + white noise; "
                          "20 = the BASELINE workload (SURVEY 8d)")
-    ap.add_argument("--source", choices=("noise", "encode", "dub"), default="noise",
+    ap.add_argument("--source", choices=("noise", "encode", "dub", "partial"), default="noise",
                     help="what the source stream is beside the planted offset: `noise` = the destination + white noise at --snr (the "
                          "BASELINE workload); `encode` = another encode of it (gain 0.7, 4 kHz low-pass, requantised to 8 bits: "
                          "synth.make_src_pcm_other_encode); `dub` = the same music bed under each stream's OWN speech on half of the "
-                         "time (synth.make_dub_pcm) -- what Sushi's real inputs look like")
+                         "time (synth.make_dub_pcm); `partial` = the source is the destination (+ noise at --snr) for the first half "
+                         "of the programme and OTHER audio for the second half (a different cut: half of the events find nothing) -- "
+                         "what Sushi's real inputs look like")
     ap.add_argument("--unrelated", action="store_true",
                     help="the source stream is INDEPENDENT audio of the same kind (no match anywhere: nothing the pair "
                          "exclusion can use) -- the worst case of a data-dependent step; parity is then the oracle sample only")
@@ -384,6 +386,12 @@ def main():
         base_pcm = None
         if args.source == "dub":
             dst_pcm, src_pcm, _ = synth.make_dub_pcm(seconds, int(round(args.offset * rate)), rate, seed=seed)
+        elif args.source == "partial":
+            dst_pcm = synth.make_dst_pcm(seconds, rate, seed=seed)
+            other = synth.make_dst_pcm(seconds, rate, seed=seed + 7777)
+            half = dst_pcm.shape[0] // 2
+            src_pcm = synth.make_src_pcm(np.concatenate([dst_pcm[:half + int(round(args.offset * rate))], other[half + int(round(args.offset * rate)):]]),
+                                         int(round(args.offset * rate)), snr_db=args.snr, seed=seed + 1)
         elif args.source == "encode":
             dst_pcm = synth.make_dst_pcm(seconds, rate, seed=seed)
             src_pcm = synth.make_src_pcm_other_encode(dst_pcm, int(round(args.offset * rate)), rate, seed=seed + 1)
@@ -515,6 +523,9 @@ def main():
     # oracle has to find the very same position.  Every rank holds the same gathered results and reaches the same
     # verdict by itself (the oracle runs in-process on the few events concerned), so all ranks leave together.
     planted_mask = ~hard_mask if not args.unrelated else np.zeros(n_total, bool)      # --unrelated: no planted answer at all
+    if args.source == "partial":
+        # the second half of the source is other audio: its events have no planted answer (the oracle sample covers them)
+        planted_mask &= np.array([(e_ * rate) < (int(round(seconds * rate)) // 2) for _, e_ in events])
     if args.source == "dub":
         # an event under the dub's own speech has no planted answer either (the louder part of its pattern is not in the
         # destination): the planted check is for the events that lie in the shared bed alone, the oracle sample covers both kinds
@@ -530,7 +541,7 @@ def main():
     if off_planted:
         worst = float(v_err[planted_mask].max())
         # (below 20 dB the true minimum wanders further from the planted position: the oracle alone decides then)
-        if args.source != "dub" and (len(off_planted) > 32 or (worst > 2.0 and args.snr >= 20.0)):
+        if args.source not in ("dub", "partial") and (len(off_planted) > 32 or (worst > 2.0 and args.snr >= 20.0)):
             raise SystemExit("verification pass: planted offset not recovered on %d events (max error %.3f samples)"
                              % (len(off_planted), worst))
         _cpu_ctx.update(dst=dst.data[0], src=src.data[0], offs=offs, lens=lens, wst=wst, npos=npos, method=args.method)
@@ -788,7 +799,8 @@ def main():
                        "source_snr_db": args.snr if args.source == "noise" else None, "source_unrelated_to_destination": bool(args.unrelated),
                        "source_kind": {"noise": "destination advanced by the offset + white noise",
                                        "encode": "another encode: gain 0.7, 4 kHz low-pass, requantised to 8 bits",
-                                       "dub": "shared music bed, each stream's own speech on half of the time"}[args.source],
+                                       "dub": "shared music bed, each stream's own speech on half of the time",
+                                       "partial": "first half of the programme: the destination + white noise; second half: other audio"}[args.source],
                        "method": METHOD_TEXT[args.method],
                        "path": ("overlap-save FFT (f32) + exact float64 re-evaluation of the near-minimum positions"
                                 if args.path == "fft" else "direct exact-f32 MFMA sliding dot product"),
