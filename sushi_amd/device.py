@@ -29,8 +29,15 @@ def _require_gpu(device=None):
     return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
 
 
-_warm = {"thread": None, "done": False, "ms": None, "error": None}
+_warms = {}                    # device index -> {"thread", "done", "ms", "error"}: one start-up per device (it was one per process)
 _warm_lock = threading.Lock()
+
+
+def _warm_key(device):
+    if device is None:
+        return torch.cuda.current_device() if torch.cuda.is_available() else -1
+    d = torch.device(device)
+    return d.index if d.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else -1)
 
 
 def warm_up(device=None, background=False):
@@ -38,10 +45,12 @@ def warm_up(device=None, background=False):
     object -- 0.09-0.15 s that otherwise sit in front of the first stream (tools/setup_probe.py: a 64 K-sample stream costs 93 ms
     as the first call of a process, a 2-h stream 8 ms as a later one).  A one-shot job calls it first thing, with
     background=True, and has it behind itself by the time its audio is demuxed / decoded (the reference spends seconds there,
-    sushi.py:649-650 ffmpeg demux); a later call -- or the first DeviceStream -- waits for it.  Idempotent; returns the milliseconds the
-    start-up took (None while a background one is still running).  Do not fork after calling it."""
+    sushi.py:649-650 ffmpeg demux); a later call -- or the first DeviceStream on that device -- waits for it.  Idempotent per device;
+    returns the milliseconds the start-up took (None while a background one is still running).  Do not fork after calling it."""
+    key = _warm_key(device)
     with _warm_lock:
-        if _warm["thread"] is None:
+        w = _warms.setdefault(key, {"thread": None, "done": False, "ms": None, "error": None})
+        if w["thread"] is None:
             def work():
                 t0 = time.perf_counter()
                 try:
@@ -51,24 +60,27 @@ def warm_up(device=None, background=False):
                         tiny.searchable()
                         torch.cuda.synchronize(dev)
                 except Exception as e:                  # (the real call that follows raises the same, where it can be handled)
-                    _warm["error"] = e
-                _warm["ms"] = (time.perf_counter() - t0) * 1e3
-                _warm["done"] = True
-            _warm["thread"] = threading.Thread(target=work, name="sushi_amd-warm-up", daemon=True)
-            _warm["thread"].start()
-        t = _warm["thread"]
+                    w["error"] = e
+                w["ms"] = (time.perf_counter() - t0) * 1e3
+                w["done"] = True
+            w["thread"] = threading.Thread(target=work, name="sushi_amd-warm-up-%s" % key, daemon=True)
+            w["thread"].start()
+        t = w["thread"]
     if background:
-        return _warm["ms"] if _warm["done"] else None
+        return w["ms"] if w["done"] else None
     t.join()
-    if _warm["error"] is not None:
-        raise _warm["error"]
-    return _warm["ms"]
+    if w["error"] is not None:
+        raise w["error"]
+    return w["ms"]
 
 
-def _join_warm_up():
-    """A warm-up in flight finishes before anything else touches the GPU (its errors are the real call's to raise)."""
-    t = _warm["thread"]
-    if t is not None and not _warm["done"] and t is not threading.current_thread():
+def _join_warm_up(device=None):
+    """A warm-up in flight on this device finishes before anything else touches it (its errors are the real call's to raise)."""
+    w = _warms.get(_warm_key(device))
+    if w is None:
+        return
+    t = w["thread"]
+    if t is not None and not w["done"] and t is not threading.current_thread():
         t.join()
 
 
@@ -92,7 +104,7 @@ class DeviceStream(object):
         of those dtypes that already lives on the GPU (used as is)."""
         self._handle = None
         if _wait_for_warm_up:
-            _join_warm_up()
+            _join_warm_up(samples.device if isinstance(samples, torch.Tensor) and samples.is_cuda else device)
         on_device = isinstance(samples, torch.Tensor)
         if on_device:
             if samples.dim() != 1 or not samples.is_cuda or not samples.is_contiguous():
