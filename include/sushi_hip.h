@@ -261,7 +261,8 @@ SUSHI_HIP_API int sushi_hip_batch_diagnostics(SushiHipBatch* batch, SushiHipBatc
 /* FFT path, after a run: the lower bound of the scores of every block pair of the LAST sub-batch (slb_host[pairs]; -inf = no
  * bound) and what it was put together from (acc_host[pairs][2], in the units of the stored products.  Whole-row form: the bound of
  * the cross term's magnitude, the largest row energy of a wave; band-split form: the SIGNED upper bound of the low band's part of the
- * cross term -- sqrt(2) and bin 0 in it --, the low row's energy) -- for tests and tools that look at how sharp the exclusion is.  *n_pairs
+ * cross term -- sqrt(2) and bin 0 in it --, the low row's energy; the energies only under SUSHI_HIP_BOUND_STATISTICAL, whose term they
+ * feed: the worst-case bound does not form them) -- for tests and tools that look at how sharp the exclusion is.  *n_pairs
  * in: the capacity of the arrays, out: how many pairs there are.  Synchronises. */
 SUSHI_HIP_API int sushi_hip_batch_pair_bounds(SushiHipBatch* batch, float* slb_host, float* acc_host, int64_t* n_pairs);
 /* FFT path, after a run, for tests and tools: where the LAST sub-batch's pattern spectra and products live in the batch's workspace

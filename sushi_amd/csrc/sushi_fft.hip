@@ -577,8 +577,14 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
                 const int per_pair = band ? 1 : 16;                  // bound_low_kernel: a wave per pair
                 const int64_t want = (sbt.pairs * per_pair + BOUND_THREADS / 64 - 1) / (BOUND_THREADS / 64);
                 const unsigned grid = (unsigned)std::min<int64_t>(want, 256 * (band ? 3 : 4));   // (what is resident at each kernel's registers)
-                if (band) hipLaunchKernelGGL(bound_low_kernel, dim3(grid), dim3(BOUND_THREADS), 0, st, ba);
-                else hipLaunchKernelGGL(bound_kernel, dim3(grid), dim3(BOUND_THREADS), 0, st, ba);
+                // (the row energies are the statistical model's: the worst case -- the default -- does without them)
+                if (band) {
+                    if (ba.worst_case) hipLaunchKernelGGL(bound_low_kernel<false>, dim3(grid), dim3(BOUND_THREADS), 0, st, ba);
+                    else hipLaunchKernelGGL(bound_low_kernel<true>, dim3(grid), dim3(BOUND_THREADS), 0, st, ba);
+                } else {
+                    if (ba.worst_case) hipLaunchKernelGGL(bound_kernel<false>, dim3(grid), dim3(BOUND_THREADS), 0, st, ba);
+                    else hipLaunchKernelGGL(bound_kernel<true>, dim3(grid), dim3(BOUND_THREADS), 0, st, ba);
+                }
                 if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
                 if (launch_slb(ba) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             }
