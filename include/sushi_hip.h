@@ -32,12 +32,14 @@
 extern "C" {
 #endif
 
-#define SUSHI_HIP_ABI_VERSION 12  /* 10: band-split exclusion (low-band rows + row norms behind the spectra, SUSHI_HIP_EXCLUDE_BAND / _WHOLE,
+#define SUSHI_HIP_ABI_VERSION 13  /* 10: band-split exclusion (low-band rows + row norms behind the spectra, SUSHI_HIP_EXCLUDE_BAND / _WHOLE,
                                      SushiHipBatchDiag.excluded_audited / .max_slb_ratio_excluded / .slb_violations / .band / .band_votes);
                                      11: SushiHipBatchDiag.second_look_audited (appended);
                                      12: sushi_hip_batch_set_bound_model (the excluded side of the pair exclusion is a worst-case bound by
                                      default), the band is |f| < N/8 strictly (bin 7N/8 of a low row is zero and counted with the rest), sushi_hip_batch_reset,
-                                     sushi_hip_batch_workspace_view, SUSHI_HIP_ENOMEM / _EINTERNAL */
+                                     sushi_hip_batch_workspace_view, SUSHI_HIP_ENOMEM / _EINTERNAL;
+                                     13: SushiHipBatchInfo.lanes (appended): a large batch's sub-batches run side by side on HIP streams
+                                     of the batch's own, forked off and joined back into the stream a run is given */
 
 #if defined(__GNUC__)
 #define SUSHI_HIP_API __attribute__((visibility("default")))
@@ -141,7 +143,8 @@ typedef struct SushiHipBatchInfo {
     int32_t n_search;
     int32_t path;
     int32_t variant;          /* direct path: tile-size variant in use */
-    int32_t sub_batches;      /* FFT path: launches of each kernel per run (the batch is cut to fit the workspace) */
+    int32_t sub_batches;      /* FFT path: launches of each kernel per run (the batch is cut to fit the workspace, or -- a large batch --
+                                 into parts that run side by side: `lanes`) */
     int64_t direct_tiles;
     int64_t fft_pairs;        /* FFT path: block pairs (inverse transforms) of the whole batch */
     int64_t fft_segments;     /* FFT path: pattern segments (forward transforms) of the whole batch */
@@ -149,6 +152,12 @@ typedef struct SushiHipBatchInfo {
     uint64_t mem_bytes;       /* what sushi_hip_batch_bytes returned */
     double flops;             /* 2 * P * M summed over the requests (the direct form's work) */
     double algorithmic_bytes; /* every search and pattern sample once + 8 bytes out per request */
+    int32_t lanes;            /* FFT path: HIP streams the sub-batches of a run are spread over (1: all on the stream the run is given).
+                                 Lane 0 IS that stream; the others belong to the batch, start behind the run's first launch and are
+                                 joined before its last, so the caller sees one stream's ordering.  The stages of the path are bound by
+                                 different things (stores, instruction issue, LDS, HBM reads): side by side they fill each other's gaps.
+                                 SUSHI_HIP_LANES="subs:lanes" in the environment when the batch is created overrides the choice. */
+    int32_t reserved;
 } SushiHipBatchInfo;
 
 typedef struct SushiHipBatchDiag {

@@ -22,7 +22,7 @@ METHODS = {"sqdiff_normed": METHOD_SQDIFF_NORMED, "ccoeff_normed": METHOD_CCOEFF
 VIEW_XC, VIEW_S1, VIEW_S2, VIEW_UREL, VIEW_BASE, VIEW_SPECTRA, VIEW_USREL, VIEW_BASE1, VIEW_COARSE, VIEW_SPECTRA_LOW, \
     VIEW_ZNORM_REST = range(11)
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 NSTAGES = 6
 STAGE_NAMES = ("tspec", "mac", "ifft", "refine", "finish", "bound")
 STAGE_KERNELS = {"tspec": "tspec_kernel", "mac": "mac_kernel", "ifft": "mac_list_kernel+mac_rows_kernel+ifft_kernel", "refine": "refine_kernel",
@@ -46,7 +46,8 @@ class BatchInfo(ctypes.Structure):
     _fields_ = [("n_search", ctypes.c_int32), ("path", ctypes.c_int32), ("variant", ctypes.c_int32),
                 ("sub_batches", ctypes.c_int32), ("direct_tiles", ctypes.c_int64), ("fft_pairs", ctypes.c_int64),
                 ("fft_segments", ctypes.c_int64), ("workspace_bytes", ctypes.c_uint64), ("mem_bytes", ctypes.c_uint64),
-                ("flops", ctypes.c_double), ("algorithmic_bytes", ctypes.c_double)]
+                ("flops", ctypes.c_double), ("algorithmic_bytes", ctypes.c_double), ("lanes", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 class BatchDiag(ctypes.Structure):

@@ -51,6 +51,7 @@
 #include <stdint.h>
 #include <float.h>
 #include <limits.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -102,6 +103,7 @@ struct SushiHipBatch {
     int audit_every;                    // one search in this many has one excluded pair transformed as a check, per run
     int bound_model;                    // SUSHI_HIP_BOUND_WORST_CASE (default) / _STATISTICAL: how the excluded side's roundings enter slb
     int last_band;                      // form of the exclusion the last run's last sub-batch used (-1: none)
+    bool last_whole_cut;                // the last run took the plan's one-sub-batch cut (Plan::subs_whole)
     // AUTO learns from its own runs: a batch whose exclusion excluded next to nothing (searches without a match anywhere) runs
     // without it from then on, looking again every 64th run.  The last run's counts come back through 16 bytes of pinned host memory
     // behind an event that is only ever QUERIED: a run never waits for an earlier one.
@@ -125,7 +127,17 @@ struct SushiHipBatch {
     hipStream_t last_stream;
     bool ran;
     hipEvent_t uploaded;                // recorded on the create-time stream behind the descriptor / plan uploads
+    // lanes (sushi_fft_plan.inc): lane 0 is the stream a run is given; the others are the batch's own, forked off it behind the
+    // run's first launch and joined before its last
+    hipStream_t lane_stream[MAX_LANES];
+    hipEvent_t lane_done[MAX_LANES];
+    hipEvent_t fork;
     ~SushiHipBatch() {
+        for (int l = 1; l < MAX_LANES; ++l) {
+            if (lane_stream[l]) { (void)hipStreamSynchronize(lane_stream[l]); (void)hipStreamDestroy(lane_stream[l]); }
+            if (lane_done[l]) (void)hipEventDestroy(lane_done[l]);
+        }
+        if (fork) (void)hipEventDestroy(fork);
         if (uploaded) (void)hipEventDestroy(uploaded);
         if (stats_pending && stats_ready) (void)hipEventSynchronize(stats_ready);       // the last run's counts may still be on their way
         if (stats_ready) (void)hipEventDestroy(stats_ready);
@@ -192,11 +204,10 @@ size_t sushi_hip_batch_bytes(const SushiHipRequest* req_host, int n, int path, i
     std::vector<SearchDesc> descs;
     int64_t tiles;
     if (make_descs(req_host, n, variant, descs, &tiles) != SUSHI_HIP_OK) return 0;
-    if (path == SUSHI_HIP_PATH_DIRECT) return batch_layout(n, path, 0, 0, 0).total;
-    const size_t ws = resolve_ws(descs, workspace_cap_bytes);
+    if (path == SUSHI_HIP_PATH_DIRECT) return batch_layout(n, path, 0, 0, 0, 0, 0).total;
     Plan plan;
-    if (build_plan(descs, ws, plan) != SUSHI_HIP_OK) return 0;
-    return batch_layout(n, path, plan.pairs, plan.items.size(), ws).total;
+    if (make_plan(descs, workspace_cap_bytes, plan) != SUSHI_HIP_OK) return 0;
+    return batch_layout(n, path, plan.order.size(), plan.items.size(), plan.ws_bytes, plan.subs.size(), plan.segs).total;
 } catch (...) { return 0; }        // std::bad_alloc etc.: nothing crosses the C boundary
 
 // requests -> descriptors, plan and layout of `b` (all three replaced together or not at all), uploaded on `st`.
@@ -214,14 +225,12 @@ static int plan_and_upload(SushiHipBatch* b, const SushiHipRequest* req_host, in
         flops += 2.0 * (double)r.n_pos * (double)r.tmpl_len;
         abytes += width * ((double)r.n_pos + r.tmpl_len - 1) + width * r.tmpl_len + 8.0;
     }
-    size_t ws = 0;
     Plan plan;
     if (b->path == SUSHI_HIP_PATH_FFT) {
-        ws = resolve_ws(descs, b->ws_cap);
-        rc = build_plan(descs, ws, plan);
+        rc = make_plan(descs, b->ws_cap, plan);
         if (rc != SUSHI_HIP_OK) return rc;
     }
-    const BatchLayout lay = batch_layout(n, b->path, plan.pairs, plan.items.size(), ws);
+    const BatchLayout lay = batch_layout(n, b->path, plan.order.size(), plan.items.size(), plan.ws_bytes, plan.subs.size(), plan.segs);
     if (b->mem_bytes < lay.total) return SUSHI_HIP_ENOSPACE;
     // an earlier plan's upload reads the handle's host buffer until its event has passed
     if (b->uploaded && hipEventSynchronize(b->uploaded) != hipSuccess) return SUSHI_HIP_ELAUNCH;
@@ -276,7 +285,9 @@ int sushi_hip_batch_create(const SushiHipStream* dst, const SushiHipStream* src,
         if (m && !strcmp(m, "statistical")) b->bound_model = SUSHI_HIP_BOUND_STATISTICAL;
     }
     b->mem = (char*)mem_dev; b->mem_bytes = mem_bytes; b->ws_cap = workspace_cap_bytes;
-    b->last_stream = nullptr; b->ran = false; b->uploaded = nullptr; b->n_tiles = 0; b->direct_pairs = 0;
+    b->last_stream = nullptr; b->ran = false; b->uploaded = nullptr; b->n_tiles = 0; b->direct_pairs = 0; b->last_whole_cut = false;
+    for (int l = 0; l < MAX_LANES; ++l) { b->lane_stream[l] = nullptr; b->lane_done[l] = nullptr; }
+    b->fork = nullptr;
     const int rc = plan_and_upload(b, req_host, n, (hipStream_t)hip_stream);
     if (rc != SUSHI_HIP_OK) return rc;
     *out = guard.release();
@@ -299,6 +310,7 @@ int sushi_hip_batch_info(const SushiHipBatch* b, SushiHipBatchInfo* info) {
     info->fft_pairs = b->plan.pairs; info->fft_segments = b->plan.segs;
     info->workspace_bytes = b->plan.ws_bytes; info->mem_bytes = b->lay.total;
     info->flops = b->flops; info->algorithmic_bytes = b->algorithmic_bytes;
+    info->lanes = b->path == SUSHI_HIP_PATH_FFT ? b->plan.lanes : 1;
     return SUSHI_HIP_OK;
 }
 
@@ -332,7 +344,7 @@ int sushi_hip_batch_set_bound_model(SushiHipBatch* b, int model) {
 
 int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, float* out_score_dev, void* hip_stream) try {
     if (!b || !out_idx_dev || !out_score_dev) return SUSHI_HIP_EINVAL;
-    hipStream_t st = (hipStream_t)hip_stream;
+    const hipStream_t st0 = (hipStream_t)hip_stream;
     const SushiHipStream* dst = b->dst;
     const SushiHipStream* src = b->src;
     const int n_search = b->n;
@@ -343,17 +355,18 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
     r.dst_raw = dst->raw; r.src_raw = src->raw; r.dtype = dst->dtype;
     const SearchDesc* searches_dev = (const SearchDesc*)(b->mem + b->lay.desc);
     unsigned long long* keys = (unsigned long long*)(b->mem + b->lay.keys);
-    b->last_stream = st; b->ran = true; b->direct_pairs = 0;
-    if (hipStreamWaitEvent(st, b->uploaded, 0) != hipSuccess) return SUSHI_HIP_ELAUNCH;   // descriptors and plan have landed
+    b->last_stream = st0; b->ran = true; b->direct_pairs = 0;
+    if (hipStreamWaitEvent(st0, b->uploaded, 0) != hipSuccess) return SUSHI_HIP_ELAUNCH;   // descriptors and plan have landed
     if (b->path == SUSHI_HIP_PATH_DIRECT)
         return launch_direct(r, searches_dev, n_search, (int)b->n_tiles, b->variant, b->method, keys, out_idx_dev,
-                             out_score_dev, b->packed_out, st);
+                             out_score_dev, b->packed_out, st0);
 
     if (!(delta >= 3.8e-6) || delta > 1.0) return SUSHI_HIP_EINVAL;      // the floor covers the scoring arithmetic's own rounding
     unsigned long long* gkeys = keys + n_search;
     int* flags = (int*)(b->mem + b->lay.flags);
     int* flag_list = (int*)(b->mem + b->lay.flag_list);
-    int* sub_flagged = (int*)(b->mem + b->lay.sub_flagged);
+    char* subc = b->mem + b->lay.subc;                            // SUBC_BYTES per sub-batch: SubCounters, then its scount words
+    float* tnorm_all = (float*)(b->mem + b->lay.tnorm);           // [all segments] squared norms of the pattern rows outside the band
     RunCounters* counters = (RunCounters*)(b->mem + b->lay.counters);
     const int32_t* order = (const int32_t*)(b->mem + b->lay.order);
     const int32_t* items = (const int32_t*)(b->mem + b->lay.items);
@@ -361,9 +374,8 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
     if (g_prof_on) { g_prof.emplace_back(); pc = &g_prof.back(); }
     int* viol = (int*)(b->mem + b->lay.viol);
     // Everything a run clears before its first kernel, in ONE launch: result keys (all ones), flags / violation marks / flag list /
-    // per-sub-batch counters / run counters (one contiguous zero span of the batch's layout), and -- a batch of one sub-batch -- the
-    // pattern rows' norm accumulators, the sub-batch's small counters and, while they are small, its candidate rows.
-    const bool one_sub = b->plan.subs.size() == 1;
+    // every sub-batch's small counters / the pattern rows' norm accumulators / run counters (one contiguous zero span of the batch's
+    // layout), and -- a batch of one sub-batch, while they are small -- its candidate rows.
     bool cand_filled = false;
     {
         FillArgs fa;
@@ -371,16 +383,13 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         auto add = [&](void* p, size_t bytes, uint32_t v) { fa.p[fa.n] = (uint32_t*)p; fa.words[fa.n] = (uint32_t)(bytes / 4); fa.value[fa.n] = v; ++fa.n; };
         add(keys, (size_t)2 * n_search * sizeof(uint64_t), 0xffffffffu);
         add(flags, b->lay.counters + align_up(sizeof(RunCounters), 256) - b->lay.flags, 0u);
-        if (one_sub) {
+        if (b->plan.subs.size() == 1) {
             const SubBatch& s0 = b->plan.subs[0];
             const WsLayout w0 = ws_layout(s0.pairs, s0.segs, s0.b0 - s0.a0);
-            char* wsp0 = b->mem + b->lay.ws;
-            add(wsp0 + w0.tnorm_rest, align_up((size_t)s0.segs * sizeof(float), 16), 0u);
-            add(wsp0 + w0.scount, 256, 0u);
             const size_t cand_bytes = (size_t)s0.pairs * FFT_ROW * sizeof(unsigned long long);
-            if (cand_bytes <= ((size_t)8 << 20)) { add(wsp0 + w0.cand, cand_bytes, 0xffffffffu); cand_filled = true; }
+            if (cand_bytes <= ((size_t)8 << 20)) { add(b->mem + b->lay.ws + w0.cand, cand_bytes, 0xffffffffu); cand_filled = true; }
         }
-        if (launch_fill(fa, st) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+        if (launch_fill(fa, st0) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
     }
     const unsigned run_seq = b->run_seq++;
     const bool ccm = b->method == SUSHI_HIP_METHOD_CCOEFF_NORMED;
@@ -398,13 +407,37 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
     const bool suspended_now = b->exclusion == SUSHI_HIP_EXCLUDE_AUTO && b->suspended && ((run_seq - b->suspended_at) & 63u) != 63u;
     b->last_suspended = suspended_now ? 1 : 0;
     bool excluded_any = false;
+    // The lanes: the batch's own streams start behind the fill, the caller's stream goes on behind them (below).  Side by side pays
+    // where the stages differ in what bounds them -- the band-split form; whole rows for every pair (the whole-row form, no
+    // exclusion at all) are HBM traffic from the first kernel to the last and only contend: those runs keep their sub-batches on
+    // the caller's stream, one after the other (measured at BASELINE configs[2]: unrelated audio 25.1 ms on one stream, 26.8 side by side).
+    const bool whole_rows_throughout = suspended_now || b->exclusion == SUSHI_HIP_EXCLUDE_NEVER || b->exclusion == SUSHI_HIP_EXCLUDE_WHOLE ||
+                                       ((b->exclusion == SUSHI_HIP_EXCLUDE_AUTO || b->exclusion == SUSHI_HIP_EXCLUDE_ALWAYS) && b->band == 0 &&
+                                        b->band_decided_method == b->method);
+    const bool whole_cut = whole_rows_throughout && !b->plan.subs_whole.empty();
+    const std::vector<SubBatch>& subs = whole_cut ? b->plan.subs_whole : b->plan.subs;
+    const int lanes = whole_rows_throughout ? 1 : b->plan.lanes;
+    b->last_whole_cut = whole_cut;
+    hipStream_t lane_st[MAX_LANES] = {st0, st0, st0, st0};
+    if (lanes > 1) {
+        if (!b->fork && hipEventCreateWithFlags(&b->fork, hipEventDisableTiming) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+        if (hipEventRecord(b->fork, st0) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+        for (int l = 1; l < lanes; ++l) {
+            if (!b->lane_stream[l] && hipStreamCreateWithFlags(&b->lane_stream[l], hipStreamNonBlocking) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+            if (!b->lane_done[l] && hipEventCreateWithFlags(&b->lane_done[l], hipEventDisableTiming) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+            if (hipStreamWaitEvent(b->lane_stream[l], b->fork, 0) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+            lane_st[l] = b->lane_stream[l];
+        }
+    }
 
-    // (A two-stream variant that overlapped the multiply-accumulate of sub-batch n+1 with the inverse
-    // transforms of sub-batch n was measured 5 % slower: both kernels only contend.)
-    for (const SubBatch& sbt : b->plan.subs) {
+    // Sub-batches of a plan on lanes run side by side (sushi_fft_plan.inc "Lanes"); the others one after the other.
+    for (size_t si = 0; si < subs.size(); ++si) {
+        const SubBatch& sbt = subs[si];
+        const hipStream_t st = lane_st[sbt.lane];
         const int n_sub = sbt.b0 - sbt.a0;
         const WsLayout wl = ws_layout(sbt.pairs, sbt.segs, n_sub);
-        char* wsp = b->mem + b->lay.ws;
+        char* wsp = b->mem + b->lay.ws + (size_t)sbt.lane * b->plan.ws_lane;
+        SubCounters* subcnt = (SubCounters*)(subc + si * SUBC_BYTES);
         uint32_t* tspec = (uint32_t*)(wsp + wl.tspec);
         uint4* y = (uint4*)(wsp + wl.y);
         unsigned long long* cand = (unsigned long long*)(wsp + wl.cand);
@@ -415,8 +448,8 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         int32_t* candbuf = (int32_t*)(wsp + wl.candbuf);
         uint4* tspec_low = (uint4*)(wsp + wl.tspec_low);
         uint4* ylow = (uint4*)(wsp + wl.ylow);
-        float* tnorm_rest = (float*)(wsp + wl.tnorm_rest);
-        int* scount = (int*)(wsp + wl.scount);
+        float* tnorm_rest = tnorm_all + sbt.first_seg;
+        int* scount = (int*)subcnt + SUBC_SCOUNT;
 
         hipEvent_t t0 = prof_begin(pc, st);
         TspecArgs ta;
@@ -424,7 +457,6 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         ta.tspec = tspec; ta.sub_first_pair = sbt.first_pair; ta.pairmap = pairmap; ta.tconst = tconst;
         ta.src_s1 = src->s1; ta.src_s2 = src->s2; ta.centre = r.centre; ta.dst_stats = dst->stats; ta.method = b->method;
         ta.tspec_low = tspec_low; ta.tnorm_rest = tnorm_rest;
-        if (!one_sub && hipMemsetAsync(tnorm_rest, 0, (size_t)sbt.segs * sizeof(float), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
         if (src->dtype == SUSHI_HIP_F32) hipLaunchKernelGGL(tspec_kernel<float>, dim3((unsigned)sbt.segs), dim3(FT), 0, st, ta);
         else hipLaunchKernelGGL(tspec_kernel<uint8_t>, dim3((unsigned)sbt.segs), dim3(FT), 0, st, ta);
         if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
@@ -442,7 +474,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         ba.first_search = sbt.a0; ba.dst_len = dst->n; ba.pairmap = pairmap; ba.tconst = tconst; ba.ubase = dst->base;
         ba.sbase = dst->base + (dst->blocks + 1); ba.nb = dst->blocks; ba.coarse = dst->coarse; ba.nc = dst->nc;
         ba.slb = (float*)(wsp + wl.slb); ba.n_sub = n_sub; ba.n_pairs = (int)sbt.pairs; ba.plist = (int*)(wsp + wl.plist);
-        ba.slist = (int*)(wsp + wl.slist); ba.scount = scount; ba.order = order + sbt.first_pair;
+        ba.slist = (int*)(wsp + wl.slist); ba.scount = scount; ba.order = order + sbt.order_first;
         ba.gkeys = gkeys; ba.pair_lb = pair_lb; ba.counters = counters;
         ba.acc = (float*)(wsp + wl.acc);
         ba.sub_first_seg = sbt.first_seg; ba.tnorm_rest = tnorm_rest; ba.znorm_rest = dst->znorm_rest; ba.norm_stride = dst->norm_stride; ba.band_votes = scount + 2;
@@ -533,10 +565,10 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         memset(&ia, 0, sizeof(ia));
         ia.y = (const uint2*)y; ia.dst_stats = dst->stats; ia.searches = searches_dev + sbt.a0; ia.n_sub = n_sub; ia.first_search = sbt.a0;
         ia.sub_first_pair = sbt.first_pair; ia.dst_len = dst->n; ia.delta = (float)delta; ia.cand = cand; ia.pair_lb = pair_lb; ia.gkeys = gkeys;
-        ia.pairmap = pairmap; ia.tconst = tconst; ia.order = order + sbt.first_pair;
+        ia.pairmap = pairmap; ia.tconst = tconst; ia.order = order + sbt.order_first;
         ia.urel = dst->urel; ia.nb = dst->blocks; ia.ubase = dst->base;
         ia.usrel = dst->usrel; ia.sbase = dst->base + (dst->blocks + 1);
-        ia.flags = flags; ia.flag_list = flag_list; ia.sub_flagged = sub_flagged; ia.tiles = tiles; ia.candbuf = candbuf;
+        ia.flags = flags; ia.flag_list = flag_list + sbt.a0; ia.sub = subcnt; ia.tiles = tiles; ia.candbuf = candbuf;
         ia.cand_cap = (int)cand_capacity(sbt.pairs); ia.counters = counters;
         ia.viol = viol;
         auto launch_ifft = [&](const IfftArgs& x, unsigned grid) {
@@ -605,7 +637,6 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
                 // the second look at what the bound left (header of bound_low_exact_kernel): sharper bound, shorter list
                 ba.list = ba.slist; ba.list_count = ba.scount;
                 ba.list2 = (int*)(wsp + wl.slist2); ba.list2_count = scount + 5;
-                if (!one_sub && hipMemsetAsync(scount + 4, 0, 2 * sizeof(int), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;   // (one sub-batch: cleared by the run's first launch)
                 hipLaunchKernelGGL(bound_low_exact_kernel, dim3(256 * 4), dim3(BLE_T), 0, st, ba);
                 if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
                 if (ccm) hipLaunchKernelGGL(slb_list_kernel<SUSHI_HIP_METHOD_CCOEFF_NORMED>, dim3(256 * 2), dim3(256), 0, st, ba);
@@ -643,7 +674,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             // possible slot instead: 0.3 ms of empty launches at most, against half the rate on everything behind the first eighth.
             // `ifft` took 31.6 ms at BASELINE configs[2] on a dub with TM_CCOEFF_NORMED, 160 k pairs listed: bench.py --source dub.)
             int64_t direct64 = std::min<int64_t>(sbt.pairs, std::max<int64_t>(4096, sbt.pairs / 8));
-            if (b->plan.subs.size() == 1 && (int64_t)b->last_transformed > direct64) direct64 = sbt.pairs;
+            if ((double)b->last_transformed * (double)sbt.pairs > (double)direct64 * (double)b->plan.pairs) direct64 = sbt.pairs;   // (this sub-batch's share of it)
             const unsigned direct = (unsigned)direct64;
             ip.list_first = 0; ip.list_direct = 1;
             if (launch_ifft(ip, direct) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
@@ -657,12 +688,12 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         t0 = prof_begin(pc, st);
         RefineParams rp;
         rp.r = r; rp.searches = searches_dev; rp.first_search = sbt.a0; rp.n_sub = n_sub; rp.sub_first_pair = sbt.first_pair;
-        rp.cand = cand; rp.pair_lb = pair_lb; rp.gkeys = gkeys; rp.keys = keys; rp.flags = flags; rp.flag_list = flag_list;
-        rp.sub_flagged = sub_flagged; rp.counters = counters; rp.delta = (float)delta; rp.method = b->method;
-        rp.citems = (int*)(wsp + wl.citems); rp.n_citems = (int*)(wsp + wl.scount) + 1;
+        rp.cand = cand; rp.pair_lb = pair_lb; rp.gkeys = gkeys; rp.keys = keys; rp.flags = flags; rp.flag_list = flag_list + sbt.a0;
+        rp.sub = subcnt; rp.counters = counters; rp.delta = (float)delta; rp.method = b->method;
+        rp.citems = (int*)(wsp + wl.citems); rp.n_citems = scount + 1;
         rp.viol = viol;
         ia.citems = rp.citems; ia.n_citems = rp.n_citems;
-        int rc = launch_refine(rp, st, !one_sub);
+        int rc = launch_refine(rp, st);
         if (rc != SUSHI_HIP_OK) return rc;
         prof_end(pc, t0, SUSHI_HIP_STAGE_REFINE, st);
 
@@ -675,22 +706,24 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             hipLaunchKernelGGL(collect_kernel<SUSHI_HIP_METHOD_SQDIFF_NORMED>, dim3(COLLECT_GRID), dim3(FT), 0, st, ia);
         if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
         TileParams tp;
-        tp.r = r; tp.searches = searches_dev; tp.tiles = tiles; tp.cand = candbuf; tp.keys = keys; tp.counters = counters;
+        tp.r = r; tp.searches = searches_dev; tp.tiles = tiles; tp.cand = candbuf; tp.keys = keys; tp.counters = counters; tp.sub = subcnt;
         tp.method = b->method;
         rc = launch_tiles(tp, st);
         if (rc != SUSHI_HIP_OK) return rc;
         prof_end(pc, t0, SUSHI_HIP_STAGE_FINISH, st);
     }
-    hipEvent_t t0 = prof_begin(pc, st);
-    const int rc = launch_unpack(keys, n_search, b->method, out_idx_dev, out_score_dev, b->packed_out, st);
-    prof_end(pc, t0, SUSHI_HIP_STAGE_FINISH, st);
+    for (int l = 1; l < lanes; ++l)
+        if (hipEventRecord(b->lane_done[l], lane_st[l]) != hipSuccess || hipStreamWaitEvent(st0, b->lane_done[l], 0) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+    hipEvent_t t0 = prof_begin(pc, st0);
+    const int rc = launch_unpack(keys, n_search, b->method, out_idx_dev, out_score_dev, b->packed_out, st0);
+    prof_end(pc, t0, SUSHI_HIP_STAGE_FINISH, st0);
     if (rc == SUSHI_HIP_OK && excluded_any && !b->stats_pending) {
         // what this run's exclusion left, for the runs after it (never waited for: the event is queried)
         if (!b->host_stats && hipHostMalloc((void**)&b->host_stats, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) b->host_stats = nullptr;
         if (b->host_stats && !b->stats_ready && hipEventCreateWithFlags(&b->stats_ready, hipEventDisableTiming) != hipSuccess) b->stats_ready = nullptr;
         if (b->host_stats && b->stats_ready &&
-            hipMemcpyAsync(b->host_stats, &counters->pairs_transformed, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) == hipSuccess &&
-            hipEventRecord(b->stats_ready, st) == hipSuccess)
+            hipMemcpyAsync(b->host_stats, &counters->pairs_transformed, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st0) == hipSuccess &&
+            hipEventRecord(b->stats_ready, st0) == hipSuccess)
             b->stats_pending = true;
     }
     return rc;
@@ -742,12 +775,12 @@ int sushi_hip_batch_pair_bounds(SushiHipBatch* b, float* slb_host, float* acc_ho
     if (!b || !n_pairs) return SUSHI_HIP_EINVAL;
     if (!b->ran || b->path != SUSHI_HIP_PATH_FFT || b->plan.subs.empty()) { *n_pairs = 0; return SUSHI_HIP_OK; }
     if (hipStreamSynchronize(b->last_stream) != hipSuccess) return SUSHI_HIP_ELAUNCH;
-    const SubBatch& sbt = b->plan.subs.back();
+    const SubBatch& sbt = b->last_whole_cut ? b->plan.subs_whole.back() : b->plan.subs.back();
     const WsLayout wl = ws_layout(sbt.pairs, sbt.segs, sbt.b0 - sbt.a0);
     const int64_t cap = *n_pairs;
     *n_pairs = sbt.pairs;
     if (cap < sbt.pairs) return SUSHI_HIP_ENOSPACE;
-    const char* wsp = b->mem + b->lay.ws;
+    const char* wsp = b->mem + b->lay.ws + (size_t)sbt.lane * b->plan.ws_lane;
     if (slb_host && hipMemcpy(slb_host, wsp + wl.slb, (size_t)sbt.pairs * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return SUSHI_HIP_ELAUNCH;
     if (acc_host && hipMemcpy(acc_host, wsp + wl.acc, (size_t)sbt.pairs * 2 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return SUSHI_HIP_ELAUNCH;
     return SUSHI_HIP_OK;
@@ -758,9 +791,9 @@ int sushi_hip_batch_workspace_view(SushiHipBatch* b, int which, void** ptr_dev, 
     *ptr_dev = nullptr; *bytes = 0;
     if (!b->ran || b->path != SUSHI_HIP_PATH_FFT || b->plan.subs.empty()) return SUSHI_HIP_OK;
     if (hipStreamSynchronize(b->last_stream) != hipSuccess) return SUSHI_HIP_ELAUNCH;
-    const SubBatch& sbt = b->plan.subs.back();
+    const SubBatch& sbt = b->last_whole_cut ? b->plan.subs_whole.back() : b->plan.subs.back();
     const WsLayout wl = ws_layout(sbt.pairs, sbt.segs, sbt.b0 - sbt.a0);
-    char* wsp = b->mem + b->lay.ws;
+    char* wsp = b->mem + b->lay.ws + (size_t)sbt.lane * b->plan.ws_lane;
     switch (which) {
         case SUSHI_HIP_WS_TSPEC: *ptr_dev = wsp + wl.tspec; *bytes = (size_t)sbt.segs * ROW_BYTES; break;
         case SUSHI_HIP_WS_Y: *ptr_dev = wsp + wl.y; *bytes = (size_t)sbt.pairs * ROW_BYTES; break;

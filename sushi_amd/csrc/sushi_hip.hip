@@ -342,7 +342,7 @@ void exact_tiles_kernel(TileParams a) {
     __shared__ unsigned long long red[4];
     __shared__ int run_edge[2], next_item;
     static_assert(XRUN <= XG * SPARSE_TILE_MAX, "the chains share the chunk sums' space");
-    const int n_tiles = a.counters->n_tiles;
+    const int n_tiles = a.sub->n_tiles;
     if (n_tiles == 0) return;
     const int tid = threadIdx.x;
     typedef double d2 __attribute__((ext_vector_type(2)));
@@ -354,7 +354,7 @@ void exact_tiles_kernel(TileParams a) {
     // the workgroups take them off a queue one at a time -- handed out in equal shares, some workgroups ran twice as long as others.
     for (;;) {
         __syncthreads();                                                // the previous entry's shared state is consumed
-        if (tid == 0) next_item = atomicAdd(&a.counters->tile_next, 1);
+        if (tid == 0) next_item = atomicAdd(&a.sub->tile_next, 1);
         __syncthreads();
         const int item = next_item;
         if (item >= n_tiles * split) break;
@@ -826,7 +826,7 @@ void refine_kernel(RefineParams a) {
         if (ovf || violated) {
             // keys[s_idx] stays NO_KEY for exact_tiles_kernel; gkeys[s_idx] keeps the threshold collect_kernel needs
             a.flags[s_idx] = violated ? 2 : 1;
-            a.flag_list[atomicAdd(a.sub_flagged, 1)] = s_idx;
+            a.flag_list[atomicAdd(&a.sub->sub_flagged, 1)] = s_idx;
             atomicAdd(&a.counters->n_flagged, 1);
             if (violated) atomicAdd(&a.counters->n_all_positions, 1);
         } else {
@@ -839,15 +839,6 @@ void refine_kernel(RefineParams a) {
             a.gkeys[s_idx] = (unsigned long long)__float_as_uint(best_err);
         }
     }
-}
-
-// first launch of a sub-batch's exact stages: nothing flagged yet, no tile listed yet
-__global__ void reset_sub_kernel(int* sub_flagged, int* n_citems, RunCounters* counters) {
-    *sub_flagged = 0;
-    *n_citems = 0;
-    counters->n_tiles = 0;
-    counters->tile_next = 0;
-    counters->n_cand = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1131,9 +1122,7 @@ int launch_fill(const FillArgs& a, hipStream_t st) {
     return launch_ok();
 }
 
-int launch_refine(const RefineParams& p, hipStream_t st, bool reset) {
-    if (reset) hipLaunchKernelGGL(reset_sub_kernel, dim3(1), dim3(1), 0, st, p.sub_flagged, p.n_citems, p.counters);
-    if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+int launch_refine(const RefineParams& p, hipStream_t st) {
     hipLaunchKernelGGL(refine_kernel, dim3(p.n_sub), dim3(REFINE_THREADS), 0, st, p);
     return launch_ok();
 }

@@ -66,12 +66,18 @@ struct TileDesc {
 };
 
 // Counters of one run, in device memory (zeroed at the start of a run).
+// What the exact stages of ONE sub-batch count with: every sub-batch of a plan has its own (sub-batches of a batch may run side by
+// side on several HIP streams: sushi_fft.hip "lanes"); cleared by the run's first launch.
+struct SubCounters {
+    int32_t n_tiles;          // entries of the tile list
+    int32_t tile_next;        // exact_tiles_kernel's queue: the next entry to hand out
+    int32_t n_cand;           // entries of the candidate buffer
+    int32_t sub_flagged;      // searches of this sub-batch refine_kernel flagged (entries of its part of the flag list)
+};
+
 struct RunCounters {
     int32_t n_flagged;        // searches refine_kernel could not finish from the per-pair lists
     int32_t n_all_positions;  // of those: every position (bound violated)
-    int32_t n_tiles;          // entries of the tile list (reset per sub-batch)
-    int32_t tile_next;        // exact_tiles_kernel's queue: the next entry to hand out (reset per sub-batch)
-    int32_t n_cand;           // entries of the candidate buffer (reset per sub-batch)
     unsigned long long tiles_dense, tiles_sparse, candidates;    // totals of the run
     uint32_t max_ratio_bits;  // float bits of SushiHipBatchDiag.max_bound_ratio
     uint32_t max_ratio_audit_bits;  // float bits of SushiHipBatchDiag.max_bound_ratio_noncandidate
@@ -103,7 +109,7 @@ struct RefineParams {
     unsigned long long* keys;         // [all searches] result keys
     int* flags;                       // [all searches]
     int* flag_list;                   // [n_sub] flagged searches of this sub-batch (global indices)
-    int* sub_flagged;                 // [1] how many
+    SubCounters* sub;                 // this sub-batch's counters (sub_flagged: how many)
     int* citems;                      // [pairs of the sub-batch] out: the pairs of flagged searches collect_kernel has to look at
     int* n_citems;                    // [1] how many
     RunCounters* counters;
@@ -111,13 +117,12 @@ struct RefineParams {
     int method;                       // SUSHI_HIP_METHOD_*
     const int* viol;                  // [all searches] or NULL: 1 = a pair's lower bound was found above a real score (ifft_kernel's audit)
 };
-// `reset`: first clear the sub-batch's flag / tile / candidate counters (one tiny launch); false when launch_fill has done it
-int launch_refine(const RefineParams& p, hipStream_t st, bool reset = true);
+int launch_refine(const RefineParams& p, hipStream_t st);
 
 // Up to FILL_RANGES ranges of 32-bit words set to a value each, in ONE launch: what a run clears before its first kernel (result
 // keys, flags, counters, the candidate rows of a small batch) used to be half a dozen hipMemsetAsync calls -- a third of the
 // launches of a drop-in find_substream call, whose cost IS its launches.
-constexpr int FILL_RANGES = 6;
+constexpr int FILL_RANGES = 8;
 struct FillArgs { uint32_t* p[FILL_RANGES]; uint32_t words[FILL_RANGES]; uint32_t value[FILL_RANGES]; int n; };
 int launch_fill(const FillArgs& a, hipStream_t st);
 
@@ -127,7 +132,8 @@ struct TileParams {
     const TileDesc* tiles;
     const int32_t* cand;              // candidate positions (relative to the search window)
     unsigned long long* keys;
-    RunCounters* counters;            // n_tiles read on the device
+    RunCounters* counters;
+    SubCounters* sub;                 // this sub-batch's tile list length and queue head (read / advanced on the device)
     int method;                       // SUSHI_HIP_METHOD_*
 };
 int launch_tiles(const TileParams& p, hipStream_t st);

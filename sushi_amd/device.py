@@ -329,6 +329,7 @@ class SearchBatch(object):
         _native.check(_native.lib().sushi_hip_batch_info(self._handle, ctypes.byref(info)), "sushi_hip_batch_info")
         self.variant = int(info.variant)
         self.sub_batches = int(info.sub_batches)
+        self.lanes = int(info.lanes)
         self.n_tiles = int(info.direct_tiles)
         self.fft_pairs, self.fft_segs = int(info.fft_pairs), int(info.fft_segments)
         self.ws_bytes = int(info.workspace_bytes)

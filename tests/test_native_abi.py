@@ -26,7 +26,7 @@ def test_library_builds_and_exports_all_declared_symbols():
 def test_host_only_entry_points():
     L = _native.lib()
     C = ctypes
-    assert L.sushi_hip_abi_version() == _native.ABI_VERSION == 12
+    assert L.sushi_hip_abi_version() == _native.ABI_VERSION == 13
     assert L.sushi_hip_strerror(0) == b"ok" and b"invalid" in L.sushi_hip_strerror(-1)
     assert L.sushi_hip_centre(_native.U8) == 128.0 and L.sushi_hip_centre(_native.F32) == 0.5
     N, B = L.sushi_hip_fft_size(), L.sushi_hip_fft_block()
@@ -85,6 +85,29 @@ def test_host_only_entry_points():
     assert 0 < direct < 1 << 16
     assert L.sushi_hip_batch_bytes(req.ctypes.data, 4, 9, -1, 0) == 0                  # unknown path
     assert L.sushi_hip_batch_bytes(req.ctypes.data, 4, _native.PATH_DIRECT, 99, 0) == 0  # unknown variant
+    # lanes: a batch cut into parts that run side by side keeps the one-sub-batch cut beside the parts (the runs that form whole
+    # rows throughout take it), so it needs what one sub-batch needs + a second schedule; a cap that cannot hold that falls back
+    # to one sub-batch after the other; a large batch takes lanes by itself
+    os.environ["SUSHI_HIP_LANES"] = "4:2"
+    try:
+        lanes = L.sushi_hip_batch_bytes(req.ctypes.data, 4, _native.PATH_FFT, -1, 0)
+        assert whole <= lanes < 1.3 * whole, (lanes, whole)                              # (four small searches: a part's fixed buffers dominate)
+        assert L.sushi_hip_batch_bytes(req.ctypes.data, 4, _native.PATH_FFT, -1, 1) == small
+        os.environ["SUSHI_HIP_LANES"] = "1:1"
+        assert L.sushi_hip_batch_bytes(req.ctypes.data, 4, _native.PATH_FFT, -1, 0) == whole
+    finally:
+        del os.environ["SUSHI_HIP_LANES"]
+    big = np.zeros(3000, _native.REQUEST_DTYPE)
+    big["win_start"] = np.arange(3000) * 28000
+    big["n_pos"], big["tmpl_len"] = 2880001, 36000
+    big["tmpl_off"] = np.arange(3000) * 28000
+    auto = L.sushi_hip_batch_bytes(big.ctypes.data, 3000, _native.PATH_FFT, -1, 0)
+    os.environ["SUSHI_HIP_LANES"] = "1:1"
+    try:
+        one = L.sushi_hip_batch_bytes(big.ctypes.data, 3000, _native.PATH_FFT, -1, 0)
+    finally:
+        del os.environ["SUSHI_HIP_LANES"]
+    assert one < auto < 1.001 * one, (auto, one)                                        # nine parts on three lanes + the one-sub-batch cut: a second schedule
     req["n_pos"][2] = 0
     assert L.sushi_hip_batch_bytes(req.ctypes.data, 4, _native.PATH_FFT, -1, 0) == 0   # malformed request
     n = C.c_int(-1)

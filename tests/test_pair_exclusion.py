@@ -423,3 +423,77 @@ def test_worst_case_and_statistical_bounds_give_the_same_results(oracle):
     for k in (0, 17, 39):
         ok, osc, _ = _oracle(oracle, d0, src.data[0], offs[k], lens[k], wst[k], npos[k])
         assert int(ref[0][k]) == ok and abs(float(ref[1].view(np.float32)[k]) - osc) <= 1e-4 * osc + 2.5e-7
+
+
+@pytest.mark.parametrize("method", ["sqdiff_normed", "ccoeff_normed"])
+@pytest.mark.parametrize("lanes", ["6:3", "5:2", "4:4", "7:1"])
+def test_sub_batches_side_by_side_on_lanes_give_the_same_bits(monkeypatch, oracle, method, lanes):
+    """A large batch is cut into sub-batches that run side by side on HIP streams of the batch's own (sushi_fft_plan.inc "Lanes",
+    SushiHipBatchInfo.lanes): every sub-batch has its own counters and every lane its own workspace, so the results are the bits of
+    the one-sub-batch run -- on the first run (which decides the exclusion's form on lane 0 while the others wait for nothing but
+    the fill), on the runs after it (a run's first launch must wait for ALL lanes of the run before), and on a lane that carries
+    several sub-batches one after the other."""
+    from sushi_amd.device import SearchBatch
+    dst, src, offs, lens, wst, npos, planted = _audio_like_job(n_events=64)
+    monkeypatch.setenv("SUSHI_HIP_LANES", "1:1")
+    one = SearchBatch(dst.device_stream(), src.device_stream(), offs, lens, wst, npos, path="fft", method=method)
+    assert one.sub_batches == 1 and one.lanes == 1
+    one.run()
+    idx, score = one.results()
+    ref = (idx.copy(), score.copy().view(np.uint32))
+    assert all(abs(int(i) - p) <= 1 for i, p in zip(idx, planted))
+    d1 = one.diagnostics()
+    monkeypatch.setenv("SUSHI_HIP_LANES", lanes)
+    k, l = (int(v) for v in lanes.split(":"))
+    b = SearchBatch(dst.device_stream(), src.device_stream(), offs, lens, wst, npos, path="fft", method=method)
+    assert b.sub_batches == k and b.lanes == l, (b.sub_batches, b.lanes)
+    assert one.ws_bytes <= b.ws_bytes < one.ws_bytes * 1.3          # (the one-sub-batch cut is kept beside the parts: whole-row runs take it)
+    for r in range(5):
+        b.run()
+        idx, score = b.results()
+        assert (idx == ref[0]).all() and (score.view(np.uint32) == ref[1]).all(), r
+        d = b.diagnostics()
+        assert d["slb_violations"] == 0 and d["all_positions"] == 0 and d["band"] == d1["band"], d
+        assert 0 < d["pairs_transformed"] < b.fft_pairs // 4, d
+    # the same plan, run in the forms that make whole rows for every pair: those runs take the plan's one-sub-batch cut on the
+    # caller's stream (they only contend side by side) -- same bits, and back to the lanes afterwards
+    from sushi_amd import _native
+    for form in ("never", "whole", "band"):
+        _native.check(_native.lib().sushi_hip_batch_set_exclusion(b.handle, _native.EXCLUSION[form]), "set_exclusion")
+        for r in range(2):
+            b.run()
+            idx, score = b.results()
+            assert (idx == ref[0]).all() and (score.view(np.uint32) == ref[1]).all(), (form, r)
+        assert b.diagnostics()["band"] == {"never": -1, "whole": 0, "band": 1}[form]
+        if form == "whole":
+            slb, acc = b.pair_bounds()                           # (of the one-sub-batch cut: every pair of the batch)
+            assert len(slb) == b.fft_pairs
+    # a handful of searches against the oracle, through the lanes
+    for kk in (0, 17, 40, 63):
+        ko, so, _ = _oracle(oracle, dst.data[0], src.data[0], offs[kk], lens[kk], wst[kk], npos[kk], method)
+        assert int(idx[kk]) == ko
+
+
+def test_lanes_with_tie_saturated_searches_and_the_tile_stage(monkeypatch):
+    """The exact stages (collect_kernel's tile list and candidate buffer, exact_tiles_kernel's queue) count with the SUB-BATCH's own
+    counters: flagged searches in several sub-batches that run side by side must not share a queue head."""
+    from sushi_amd.device import DeviceStream, SearchBatch
+    t = np.arange(400000, dtype=np.float64)
+    img = (0.5 + 0.3 * np.sin(2 * np.pi * t / 5000.0)).astype(np.float32)       # very smooth: every search is flagged
+    offs = [20000 + 30000 * k for k in range(8)]
+    lens = [6000 + 500 * k for k in range(8)]
+    wst = [max(0, o - 15000) for o in offs]
+    npos = [54001] * 8
+    res = {}
+    for lanes in ("1:1", "4:4", "8:2"):
+        monkeypatch.setenv("SUSHI_HIP_LANES", lanes)
+        b = SearchBatch(DeviceStream(img), DeviceStream(img), offs, lens, wst, npos, path="fft")
+        for r in range(2):
+            b.run()
+            idx, score = b.results()
+        d = b.diagnostics()
+        assert d["flagged"] == 8 and d["tiles_sparse"] + d["tiles_dense"] >= 8, d
+        res[lanes] = (idx.copy(), score.copy().view(np.uint32), d["tiles_sparse"], d["tiles_dense"], d["candidates"])
+    for lanes in ("4:4", "8:2"):
+        assert (res[lanes][0] == res["1:1"][0]).all() and (res[lanes][1] == res["1:1"][1]).all()
+        assert res[lanes][2:] == res["1:1"][2:]
