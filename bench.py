@@ -253,6 +253,7 @@ class DryBatch(object):
         self._score = torch.zeros(hi - lo, dtype=torch.float32)
         self.flops = self.algorithmic_bytes = 1.0
         self.sub_batches, self.variant, self.fft_pairs, self.fft_segs, self.ws_bytes, self.delta = 1, 0, 0, 0, 0, 0.0
+        self.lanes = 1
 
     def run(self):
         return self._idx, self._score
@@ -750,7 +751,10 @@ def main():
                         "step_traffic_over_algorithmic": None if step_traffic is None else
                         step_traffic / batch.algorithmic_bytes,
                         "traffic_bytes_per_kernel_per_step": per_kernel,
-                        "dominant_stage": {"stage": dom, "kernels": kname, "ms": dom_ms, "share_of_step": dom_ms / kernel_ms,
+                        # (on lanes the stages of different sub-batches run side by side: their HIP-event times add up to more than
+                        # the step, so a stage's share is its share of their SUM)
+                        "dominant_stage": {"stage": dom, "kernels": kname, "ms": dom_ms,
+                                           "share_of_step": dom_ms / max(sum(stages.values()), kernel_ms),
                                            "traffic_bytes_per_step": dom_traffic_bytes,
                                            "traffic_GBps": None if dom_traffic_bytes is None else dom_traffic_bytes / (dom_ms * 1e-3) / 1e9},
                         "traffic_key": wl_key, "traffic_source": traffic_note,
@@ -758,7 +762,11 @@ def main():
                         # the binary that actually ran (the digest above is of the sources on disk)
                         "library": loaded_library(),
                         "launches_per_step": batch.sub_batches,
+                        "sub_batches": batch.sub_batches, "lanes": batch.lanes,
                         "stage_ms": stages,
+                        "stage_ms_basis": "HIP events on the stream each sub-batch runs on, summed over the sub-batches" + (
+                            " -- which run side by side on %d HIP streams (lanes): the stages add up to more than the step; "
+                            "SUSHI_HIP_LANES=1:1 gives the one-after-the-other times" % batch.lanes if batch.lanes > 1 else ""),
                         "step_kernels_ms": kernel_ms,
                         "step_hbm_achieved_GBps": achieved,
                         "step_frac": achieved / PEAK_HBM_GBPS,

@@ -423,6 +423,8 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         if (!b->fork && hipEventCreateWithFlags(&b->fork, hipEventDisableTiming) != hipSuccess) return SUSHI_HIP_ELAUNCH;
         if (hipEventRecord(b->fork, st0) != hipSuccess) return SUSHI_HIP_ELAUNCH;
         for (int l = 1; l < lanes; ++l) {
+            // (stream priorities for the lanes -- the batch's own below the caller's, above it, one of each -- and an occupancy cap on
+            // mac_kernel<1024> were measured flat: 8.31 - 8.55 ms whatever the setting, tools/experiments/README.md)
             if (!b->lane_stream[l] && hipStreamCreateWithFlags(&b->lane_stream[l], hipStreamNonBlocking) != hipSuccess) return SUSHI_HIP_ELAUNCH;
             if (!b->lane_done[l] && hipEventCreateWithFlags(&b->lane_done[l], hipEventDisableTiming) != hipSuccess) return SUSHI_HIP_ELAUNCH;
             if (hipStreamWaitEvent(b->lane_stream[l], b->fork, 0) != hipSuccess) return SUSHI_HIP_ELAUNCH;
@@ -605,10 +607,14 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             // (bound_kernel adds to the pairs' accumulators; bound_low_kernel -- a wave per pair -- stores them)
             if (!band && hipMemsetAsync(ba.acc, 0, (size_t)sbt.pairs * 2 * sizeof(float), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
             {
-                // persistent waves: four workgroups of four per CU (the kernel's register budget), fewer for a small batch
+                // waves striding over the pairs: a small multiple of what is resident at the kernel's registers (four workgroups of four
+                // waves per CU, three for bound_low_kernel), fewer for a small batch.  Exactly what is resident -- persistent waves --
+                // leaves the hardware nothing to balance with: bound_low_kernel alone 2.41 - 2.44 ms at BASELINE configs[2] with 1 x,
+                // 2.36 with 2 x, 2.30 - 2.32 with 4 x and 8 x; next to other lanes' kernels 2 x is as good as it gets (8 x and more:
+                // the per-workgroup prologue shows)
                 const int per_pair = band ? 1 : 16;                  // bound_low_kernel: a wave per pair
                 const int64_t want = (sbt.pairs * per_pair + BOUND_THREADS / 64 - 1) / (BOUND_THREADS / 64);
-                const unsigned grid = (unsigned)std::min<int64_t>(want, 256 * (band ? 3 : 4));   // (what is resident at each kernel's registers)
+                const unsigned grid = (unsigned)std::min<int64_t>(want, 256 * (band ? 3 * (lanes > 1 ? 2 : 4) : 4));
                 // (the row energies are the statistical model's: the worst case -- the default -- does without them)
                 if (band) {
                     if (ba.worst_case) hipLaunchKernelGGL(bound_low_kernel<false>, dim3(grid), dim3(BOUND_THREADS), 0, st, ba);

@@ -13,6 +13,12 @@ run_wl() {
   rm -rf gpurun_out/prof_*
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -o kt -- $B > $O/kt_$name.log 2>&1
   cp gpurun_out/prof_kt/kt_kernel_stats.csv $O/${name}_kernel_stats.csv
+  if [ $name = cfg2 ]; then
+    # the same workload with its sub-batches one after the other on one stream: per-kernel times that add up to the step
+    rm -rf gpurun_out/prof_kt1
+    SUSHI_HIP_LANES=1:1 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt1 -o kt -- $B > $O/kt_${name}_lanes1.log 2>&1
+    cp gpurun_out/prof_kt1/kt_kernel_stats.csv $O/${name}_lanes1_kernel_stats.csv
+  fi
   timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -o fetch -- $B > $O/fetch_$name.log 2>&1
   timeout 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -o write -- $B > $O/write_$name.log 2>&1 || echo "WRITE_SIZE pass of $name cut by its timeout" | tee -a $O/notes.txt
   python tools/summarize_pmc.py $O/${name}_pmc_summary.csv $(find gpurun_out/prof_fetch gpurun_out/prof_write -name '*counter_collection.csv' 2>/dev/null)
@@ -34,6 +40,7 @@ IFS='|' read -ra X <<< "$EXTRA"
 for w in "${X[@]}"; do
   name=$(echo "$w" | cut -d: -f1); args=$(echo "$w" | cut -d: -f2-)
   case "$name" in
+    lanes1*) SUSHI_HIP_LANES=1:1 timeout 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --emulate-shards 0 --cpu-sample 128 $args > $O/bench_${name}_n1.json 2> $O/bench_${name}_n1.err ;;
     stat*) SUSHI_HIP_BOUND_MODEL=statistical timeout 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --emulate-shards 0 --cpu-sample 128 $args > $O/bench_${name}_n1.json 2> $O/bench_${name}_n1.err ;;
     *) timeout 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --emulate-shards 0 --cpu-sample 128 $args > $O/bench_${name}_n1.json 2> $O/bench_${name}_n1.err ;;
   esac
