@@ -250,6 +250,15 @@ SUSHI_HIP_API int sushi_hip_batch_set_bound_model(SushiHipBatch* batch, int mode
  * out_packed_dev (8-byte aligned, n records; NULL = off) -- the block a rank contributes to the one all-gather of the path, written
  * by the kernel that writes out_idx / out_score instead of by two copies afterwards. */
 SUSHI_HIP_API int sushi_hip_batch_set_packed_output(SushiHipBatch* batch, int32_t* out_packed_dev);
+/* The answer as soon as it exists (FFT path; v13).  early: n 16-byte records {int32 index, float32 score bits, int32 ready, int32
+ * flagged} in memory BOTH sides can touch -- pinned host memory mapped to the device (16-byte aligned; NULL = off).  The kernel that
+ * finishes a search from its candidate lists (refine_kernel) writes the search's record with ONE 16-byte store: ready = 1 and either
+ * the final (index, score bits) -- the very values out_idx / out_score receive -- or flagged = 1: the search goes on to the tile stage
+ * and its answer is in out_idx / out_score when the run's stream has drained.  A caller that sets ready = 0 in every record before a
+ * run can poll the records instead of synchronising the stream: a drop-in find_substream call then does not wait for the three
+ * launches behind refine_kernel (collection pass, exact tiles, unpack), which find nothing to do for it (~30 of ~140 us a call).
+ * The direct path writes no early records. */
+SUSHI_HIP_API int sushi_hip_batch_set_early_output(SushiHipBatch* batch, int32_t* early);
 /* One pass of the hot path over the batch.  Asynchronous, with ONE exception: the first run of a batch (and the first after its
  * method changed) that goes through the pair exclusion in AUTO or ALWAYS mode reads 8 bytes back to decide the exclusion's form and
  * synchronises `hip_stream` once for that (not capturable in a hipGraph; BAND, WHOLE and NEVER never synchronise, nor does a

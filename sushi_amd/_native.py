@@ -128,6 +128,8 @@ def lib():
     L.sushi_hip_batch_diagnostics.argtypes = [vp, ctypes.POINTER(BatchDiag), vp, vp]
     L.sushi_hip_batch_set_packed_output.restype = ci
     L.sushi_hip_batch_set_packed_output.argtypes = [vp, vp]
+    L.sushi_hip_batch_set_early_output.restype = ci
+    L.sushi_hip_batch_set_early_output.argtypes = [vp, vp]
     L.sushi_hip_batch_set_exclusion.restype = ci
     L.sushi_hip_batch_set_exclusion.argtypes = [vp, ci]
     L.sushi_hip_batch_set_bound_model.restype = ci

@@ -115,6 +115,7 @@ struct SushiHipBatch {
     unsigned suspended_at;              // run_seq of the run that showed it
     int last_suspended;                 // whether the last run was one of those
     int32_t* packed_out;                // NULL, or where every run ALSO leaves its results as 8-byte (index, score bits) records
+    int32_t* early_out;                 // NULL, or sushi_hip_batch_set_early_output's 16-byte records (memory host and device both touch)
     int64_t n_tiles;
     int64_t direct_pairs;               // pairs of the last run's sub-batches that were transformed without the exclusion
     std::vector<SearchDesc> descs;
@@ -138,7 +139,7 @@ struct SushiHipBatch {
             if (lane_done[l]) (void)hipEventDestroy(lane_done[l]);
         }
         if (fork) (void)hipEventDestroy(fork);
-        if (uploaded) (void)hipEventDestroy(uploaded);
+        if (uploaded) { (void)hipEventSynchronize(uploaded); (void)hipEventDestroy(uploaded); }    // (an upload may still read the handle's host buffers)
         if (stats_pending && stats_ready) (void)hipEventSynchronize(stats_ready);       // the last run's counts may still be on their way
         if (stats_ready) (void)hipEventDestroy(stats_ready);
         if (host_stats) (void)hipHostFree(host_stats);
@@ -273,6 +274,7 @@ int sushi_hip_batch_create(const SushiHipStream* dst, const SushiHipStream* src,
     b->dst = dst; b->src = src; b->n = n; b->path = path; b->variant = variant; b->method = SUSHI_HIP_METHOD_SQDIFF_NORMED;
     b->exclusion = SUSHI_HIP_EXCLUDE_AUTO;
     b->packed_out = nullptr;
+    b->early_out = nullptr;
     b->last_transformed = 0;
     b->host_stats = nullptr; b->stats_ready = nullptr; b->stats_pending = false; b->suspended = 0; b->suspended_at = 0; b->last_suspended = 0;
     b->band = -1; b->last_band = -1; b->band_decided_method = -1; b->band_votes[0] = b->band_votes[1] = 0; b->run_seq = 0; b->audit_every = 2;
@@ -327,6 +329,13 @@ int sushi_hip_batch_set_packed_output(SushiHipBatch* b, int32_t* out_packed_dev)
     if (!b) return SUSHI_HIP_EINVAL;
     if ((uintptr_t)out_packed_dev & 7) return SUSHI_HIP_EALIGN;
     b->packed_out = out_packed_dev;
+    return SUSHI_HIP_OK;
+}
+
+int sushi_hip_batch_set_early_output(SushiHipBatch* b, int32_t* early) {
+    if (!b) return SUSHI_HIP_EINVAL;
+    if ((uintptr_t)early & 15) return SUSHI_HIP_EALIGN;
+    b->early_out = early;
     return SUSHI_HIP_OK;
 }
 
@@ -414,6 +423,19 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
     const bool whole_rows_throughout = suspended_now || b->exclusion == SUSHI_HIP_EXCLUDE_NEVER || b->exclusion == SUSHI_HIP_EXCLUDE_WHOLE ||
                                        ((b->exclusion == SUSHI_HIP_EXCLUDE_AUTO || b->exclusion == SUSHI_HIP_EXCLUDE_ALWAYS) && b->band == 0 &&
                                         b->band_decided_method == b->method);
+    if (whole_rows_throughout && b->plan.whole_pending) {
+        // the first run that wants the one-sub-batch cut makes it (host) and uploads its schedule and items behind the fill
+        if (complete_whole_cut(b->descs, b->plan)) {
+            const size_t o0 = b->plan.whole_order_first, o1 = b->plan.order.size(), i0 = b->plan.whole_items_first, i1 = b->plan.items.size();
+            if (hipMemcpyAsync(b->mem + b->lay.order + o0 * sizeof(int32_t), b->plan.order.data() + o0, (o1 - o0) * sizeof(int32_t), hipMemcpyHostToDevice, st0) != hipSuccess ||
+                hipMemcpyAsync(b->mem + b->lay.items + i0 * sizeof(int32_t), b->plan.items.data() + i0, (i1 - i0) * sizeof(int32_t), hipMemcpyHostToDevice, st0) != hipSuccess)
+                return SUSHI_HIP_ELAUNCH;
+            // (the copies read the handle's own vectors: a re-plan and the destructor wait for this event before they touch them)
+            if (hipEventRecord(b->uploaded, st0) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+        } else {
+            b->plan.whole_pending = false;                       // (cannot happen: the room was sized for it; the parts run one after the other then)
+        }
+    }
     const bool whole_cut = whole_rows_throughout && !b->plan.subs_whole.empty();
     const std::vector<SubBatch>& subs = whole_cut ? b->plan.subs_whole : b->plan.subs;
     const int lanes = whole_rows_throughout ? 1 : b->plan.lanes;
@@ -698,6 +720,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         rp.sub = subcnt; rp.counters = counters; rp.delta = (float)delta; rp.method = b->method;
         rp.citems = (int*)(wsp + wl.citems); rp.n_citems = scount + 1;
         rp.viol = viol;
+        rp.early = reinterpret_cast<int4*>(b->early_out);
         ia.citems = rp.citems; ia.n_citems = rp.n_citems;
         int rc = launch_refine(rp, st);
         if (rc != SUSHI_HIP_OK) return rc;

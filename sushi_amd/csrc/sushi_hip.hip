@@ -603,6 +603,11 @@ __global__ void unpack_keys_kernel(const unsigned long long* __restrict__ keys, 
 // with: an exact score further from the f32 one than the bound allows means the error model does not hold for this
 // search, which is then evaluated at every position (flag 2).  One workgroup per search.
 // ------------------------------------------------------------------------------------------
+// one 16-byte store of (index, score bits, ready, flagged) into memory the host polls (sushi_hip_batch_set_early_output)
+__device__ __forceinline__ void early_store(int4* p, int idx, int score_bits, int ready, int flagged) {
+    typedef int i4v __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(i4v{idx, score_bits, ready, flagged}, reinterpret_cast<i4v*>(p));
+}
 constexpr int RCAP = 128;
 constexpr int RAUD = AUDIT_RUNS * FFT_AUDIT;      // audited non-candidate positions per search
 constexpr int RENT = RCAP + RAUD;                // list entries: candidates, then audit positions
@@ -753,7 +758,10 @@ void refine_kernel(RefineParams a) {
         // a pattern without variance: cv2 returns a result of all ones, whose first arg-max is position 0
         const TemplStats ts = templ_stats(a.r.src_s1, a.r.src_s2, sd.tmpl_off, sd.tmpl_len, a.r.centre);
         if (ts.flat) {
-            if (tid == 0) { a.keys[s_idx] = make_key_max(1.0f, 0u); a.gkeys[s_idx] = 0ull; }
+            if (tid == 0) {
+                a.keys[s_idx] = make_key_max(1.0f, 0u); a.gkeys[s_idx] = 0ull;
+                if (a.early) early_store(a.early + s_idx, 0, __float_as_int(key_score_max(make_key_max(1.0f, 0u))), 1, 0);
+            }
             return;
         }
     }
@@ -829,6 +837,7 @@ void refine_kernel(RefineParams a) {
             a.flag_list[atomicAdd(&a.sub->sub_flagged, 1)] = s_idx;
             atomicAdd(&a.counters->n_flagged, 1);
             if (violated) atomicAdd(&a.counters->n_all_positions, 1);
+            if (a.early) early_store(a.early + s_idx, 0, 0, 1, 1);      // ready, flagged: the answer comes with the run's last kernel
         } else {
             unsigned long long best = NO_KEY;
             float best_err = 0.f;
@@ -837,6 +846,11 @@ void refine_kernel(RefineParams a) {
             a.keys[s_idx] = best;
             // diagnostics: how far the ranking stage was off at the position that won
             a.gkeys[s_idx] = (unsigned long long)__float_as_uint(best_err);
+            // the answer as unpack_keys_kernel will write it, NOW, in one 16-byte store (sushi_hip_batch_set_early_output)
+            if (a.early) {
+                const float sc = a.method == SUSHI_HIP_METHOD_CCOEFF_NORMED ? key_score_max(best) : key_score(best);
+                early_store(a.early + s_idx, (int)key_pos(best), __float_as_int(sc), 1, 0);
+            }
         }
     }
 }

@@ -116,6 +116,7 @@ struct RefineParams {
     float delta;
     int method;                       // SUSHI_HIP_METHOD_*
     const int* viol;                  // [all searches] or NULL: 1 = a pair's lower bound was found above a real score (ifft_kernel's audit)
+    int4* early;                      // [all searches] or NULL: sushi_hip_batch_set_early_output's records (host memory mapped to the device)
 };
 int launch_refine(const RefineParams& p, hipStream_t st);
 

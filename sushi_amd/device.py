@@ -315,11 +315,19 @@ class SearchBatch(object):
             # host instead of two -- a fifth of what a drop-in call waits for its answer (tools/call_breakdown.py)
             self._packed = None
             self._host_rec = None
+            self._early = self._early_np = None
             if n <= 4:
                 # a drop-in call's answer is a handful of bytes: the library's last kernel writes the records straight into pinned
                 # host memory (device-visible under unified addressing) -- results() is then a wait, not a copy
                 self._host_rec = torch.empty((n, 2), dtype=torch.int32, pin_memory=True)
                 _native.check(L.sushi_hip_batch_set_packed_output(h, self._host_rec.data_ptr()), "sushi_hip_batch_set_packed_output")
+                if self.path == "fft":
+                    # ... and the kernel that finishes a search from its candidate lists leaves the answer there the moment it has it
+                    # (sushi_hip_batch_set_early_output: index, score bits, ready, flagged): results() polls these records and does
+                    # not wait for the three launches behind that kernel, which find nothing to do for such a call
+                    self._early = torch.zeros((n, 4), dtype=torch.int32, pin_memory=True)
+                    self._early_np = self._early.numpy()
+                    _native.check(L.sushi_hip_batch_set_early_output(h, self._early.data_ptr()), "sushi_hip_batch_set_early_output")
             else:
                 self.set_packed_output(torch.empty((n, 2), dtype=torch.int32, device=dev))
         self._read_info()
@@ -371,6 +379,9 @@ class SearchBatch(object):
         of `packed` (a contiguous int32 CUDA tensor [>= n, 2]) -- a rank's block of the all-gather, written by the library's last
         kernel instead of by two copies afterwards (sushi_amd.distributed.ShardedSearch).  None turns it off."""
         self._host_rec = None
+        if self._early is not None:
+            _native.check(_native.lib().sushi_hip_batch_set_early_output(self._handle, None), "sushi_hip_batch_set_early_output")
+            self._early = self._early_np = None
         if packed is None:
             _native.check(_native.lib().sushi_hip_batch_set_packed_output(self._handle, None), "sushi_hip_batch_set_packed_output")
             self._packed = None
@@ -398,6 +409,8 @@ class SearchBatch(object):
     def run(self, hip_stream=None):
         """One pass of the hot path over this batch (asynchronous)."""
         st = _raw_stream(self.dst.device) if hip_stream is None else hip_stream
+        if self._early_np is not None:
+            self._early_np[:, 2] = 0                      # not ready: results() polls
         rc = _native.lib().sushi_hip_batch_run(self._handle, self.delta, self.out_idx.data_ptr(),
                                                self.out_score.data_ptr(), st)
         _native.check(rc, "sushi_hip_batch_run")
@@ -405,6 +418,17 @@ class SearchBatch(object):
 
     def results(self):
         """(idx int32 ndarray, score float32 ndarray) -- synchronises."""
+        if self._early_np is not None:
+            # the answer as soon as the kernel that has it wrote it (a spin of a few dozen microseconds; a search that went on to
+            # the tile stage, or a GPU that takes longer than any drop-in call does, falls through to the stream's end)
+            e = self._early_np
+            t_end = time.perf_counter() + 2e-3
+            while not e[:, 2].all():
+                if time.perf_counter() > t_end:
+                    break
+            else:
+                if not e[:, 3].any():
+                    return e[:, 0].copy(), e[:, 1].copy().view(np.float32)
         if self._host_rec is not None:
             torch.cuda.current_stream(self.dst.device).synchronize()
             rec = self._host_rec.numpy()

@@ -909,3 +909,42 @@ def test_packed_output_is_the_same_results_as_8_byte_records():
         b.run()
         b.results()
         assert (packed.cpu().numpy() == -7).all()
+
+
+def test_early_records_hold_the_answer_or_say_flagged():
+    """sushi_hip_batch_set_early_output: the kernel that finishes a search from its candidate lists writes the answer as one 16-byte
+    record (index, score bits, ready, flagged) into memory the host can poll -- the very values out_idx / out_score get from the
+    run's last kernel; a search that goes on to the tile stage says so instead.  A batch of up to four searches (what a drop-in
+    find_substream call is) has such records by itself and results() reads them."""
+    import torch
+    from sushi_amd.device import DeviceStream, SearchBatch
+    rng = np.random.default_rng(5)
+    t = np.arange(120000, dtype=np.float64)
+    smooth = (0.5 + 0.3 * np.sin(2 * np.pi * t / 5000.0)).astype(np.float32)       # ties everywhere: flagged
+    noisy = (rng.standard_normal(120000) * 0.2 + 0.5).clip(0, 1).astype(np.float32)
+    img = np.concatenate([smooth, noisy])
+    offs, lens, wst, npos = [20000, 150000, 200000], [6000, 9000, 4097], [0, 130000, 170000], [54001, 60000, 50001]
+    for method in ("sqdiff_normed", "ccoeff_normed"):
+        b = SearchBatch(DeviceStream(img), DeviceStream(img), offs, lens, wst, npos, path="fft", method=method)
+        assert b._early is not None
+        for r in range(3):
+            b.run()
+            idx, score = b.results()                      # (one search flagged: falls through to the stream's end)
+            torch.cuda.synchronize()
+            e = b._early.numpy()
+            assert (e[:, 2] == 1).all() and list(e[:, 3]) == [1, 0, 0], e
+            oi, osc = b.out_idx.cpu().numpy(), b.out_score.cpu().numpy()
+            assert (idx == oi).all() and (score.view(np.uint32) == osc.view(np.uint32)).all()
+            assert (e[1:, 0] == oi[1:]).all() and (e[1:, 1].view(np.uint32) == osc[1:].view(np.uint32)).all()
+            assert wst[1] + oi[1] == offs[1] and wst[2] + oi[2] == offs[2]
+        # without the flagged search results() IS the early records (no stream synchronisation: the records are polled)
+        b2 = SearchBatch(DeviceStream(img), DeviceStream(img), offs[1:], lens[1:], wst[1:], npos[1:], path="fft", method=method)
+        b2.run()
+        idx2, score2 = b2.results()
+        assert (idx2 == oi[1:]).all() and (score2.view(np.uint32) == osc[1:].view(np.uint32)).all()
+    # a flat pattern under TM_CCOEFF_NORMED answers (0, 1.0) from refine_kernel's own early exit
+    flat = img.copy(); flat[1000:6000] = 0.5
+    b3 = SearchBatch(DeviceStream(flat), DeviceStream(flat), [1000], [5000], [0], [30001], path="fft", method="ccoeff_normed")
+    b3.run()
+    idx3, score3 = b3.results()
+    assert idx3[0] == 0 and score3[0] == 1.0 and list(b3._early.numpy()[0]) == [0, np.float32(1.0).view(np.int32), 1, 0]
