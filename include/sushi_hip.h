@@ -39,7 +39,8 @@ extern "C" {
                                      default), the band is |f| < N/8 strictly (bin 7N/8 of a low row is zero and counted with the rest), sushi_hip_batch_reset,
                                      sushi_hip_batch_workspace_view, SUSHI_HIP_ENOMEM / _EINTERNAL;
                                      13: SushiHipBatchInfo.lanes (appended): a large batch's sub-batches run side by side on HIP streams
-                                     of the batch's own, forked off and joined back into the stream a run is given */
+                                     of the batch's own, forked off and joined back into the stream a run is given;
+                                     sushi_hip_batch_set_early_output */
 
 #if defined(__GNUC__)
 #define SUSHI_HIP_API __attribute__((visibility("default")))
@@ -263,7 +264,10 @@ SUSHI_HIP_API int sushi_hip_batch_set_early_output(SushiHipBatch* batch, int32_t
  * method changed) that goes through the pair exclusion in AUTO or ALWAYS mode reads 8 bytes back to decide the exclusion's form and
  * synchronises `hip_stream` once for that (not capturable in a hipGraph; BAND, WHOLE and NEVER never synchronise, nor does a
  * batch too small for AUTO to use the exclusion -- a drop-in find_substream call).  Environment variables are read when a batch is
- * created, never here.
+ * created, never here.  A batch on lanes (SushiHipBatchInfo.lanes > 1) launches its sub-batches on streams of its own between the
+ * run's first launch and its last on `hip_stream`: what is ordered behind the run on `hip_stream` is ordered behind all of it.  The
+ * first run of such a batch that forms whole rows for every pair (whole-row form, no exclusion) builds the plan's one-sub-batch
+ * cut on the host first (milliseconds, once).
  *   out_idx_dev[n]   = result.argmin(axis=1)[0]        (wav.py:186)
  *   out_score_dev[n] = result[0][min_idx], float32     (wav.py:188)
  * delta (FFT path; > 0, <= 1): floor of the score margin inside which positions are re-evaluated exactly -- every
