@@ -549,9 +549,8 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
 
         // the multiply-accumulate over ALL pairs: of the low rows (band-split form) or of whole rows; `enable`: a device flag that
         // may call the launch off (the whole-row launch queued behind the survivors' list, below)
-        auto launch_mac = [&](const bool low, const int* enable, const int* dense_search) {
+        auto launch_mac = [&](const bool low, const int* enable, const int* items_of_the_launch) {
             MacArgs ma;
-            ma.dense_search = dense_search;
             ma.spec_blocks = dst->blocks;
             ma.searches = searches_dev + sbt.a0; ma.tconst = tconst; ma.sub_first_seg = sbt.first_seg;
             ma.sub_first_pair = sbt.first_pair;
@@ -561,7 +560,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             else { ma.spec = (const uint4*)dst->spec; ma.tspec = (const uint4*)tspec; ma.y = y; }
             for (int kern = 0; kern < 2; ++kern) {
                 if (sbt.item_count[kern] == 0) continue;
-                ma.items = items + (size_t)sbt.item_first[kern] * (1 + MAC_SPW);
+                ma.items = items_of_the_launch + (size_t)(sbt.item_first[kern] - sbt.item_first[0]) * (1 + MAC_SPW);
                 ma.n_items = sbt.item_count[kern];
                 const int chunks = (low ? LROWE : ROWE) / MAC_BW;
                 ma.chunk_group = std::min(sbt.chunk_group[kern], chunks / 8);
@@ -578,7 +577,8 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             return SUSHI_HIP_OK;
         };
         t0 = prof_begin(pc, st);
-        if (launch_mac(band != 0, nullptr, nullptr) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+        const int32_t* sub_items = items + (size_t)sbt.item_first[0] * (1 + MAC_SPW);         // (the sub-batch's two item lists lie next to each other)
+        if (launch_mac(band != 0, nullptr, sub_items) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
         prof_end(pc, t0, SUSHI_HIP_STAGE_MAC, st);
 
         t0 = prof_begin(pc, st);
@@ -674,12 +674,17 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
                 if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
                 final_list = ba.list2; final_count = ba.list2_count;
                 // whole rows of what is left: pair by pair for the searches that left few (the usual case), by the dense
-                // multiply-accumulate for the items of searches the bound could exclude little of (no match anywhere) -- decided per
-                // item of eight searches, on the device (dense_select_kernel)
+                // multiply-accumulate for the searches the bound could exclude little of (no match anywhere) -- decided per search and
+                // regrouped into items of their own, on the device (dense_search_kernel, dense_repack_kernel)
                 int* any_dense = scount + 4;                         // (zero since the run's first launch)
                 int* dense = (int*)(wsp + wl.dense_search);
-                hipLaunchKernelGGL(dense_select_kernel, dim3((unsigned)(sbt.item_count[0] + sbt.item_count[1])), dim3(64), 0, st, ba,
-                                   items + (size_t)sbt.item_first[0] * (1 + MAC_SPW), dense, any_dense);
+                int* ditems = (int*)(wsp + wl.ditems);
+                hipLaunchKernelGGL(dense_search_kernel, dim3((unsigned)n_sub), dim3(64), 0, st, ba, dense, scount + 6);
+                {
+                    const size_t second = (size_t)(sbt.item_first[1] - sbt.item_first[0]) * (1 + MAC_SPW);
+                    hipLaunchKernelGGL(dense_repack_kernel, dim3(2), dim3(REPACK_THREADS), 0, st, sub_items, sbt.item_count[0], sub_items + second,
+                                       sbt.item_count[1], dense, n_sub, ditems, ditems + second, scount + 6, (int)(sbt.pairs / 8), any_dense);
+                }
                 if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
                 {
                     MacRowsArgs ra;
@@ -692,7 +697,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
                     if (launch_ok() != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
                 }
                 if (sbt.long_patterns && launch_mac_list(final_list, final_count, (int)sbt.pairs, dense, 1) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-                if (launch_mac(false, any_dense, dense) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
+                if (launch_mac(false, any_dense, ditems) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
             }
             ip.order = final_list; ip.count = final_count; ip.audit_mark = ba.audit_mark;
             // One workgroup per list slot up to what the list usually holds (an eighth of the pairs: empty slots there cost a

@@ -497,3 +497,44 @@ def test_lanes_with_tie_saturated_searches_and_the_tile_stage(monkeypatch):
     for lanes in ("4:4", "8:2"):
         assert (res[lanes][0] == res["1:1"][0]).all() and (res[lanes][1] == res["1:1"][1]).all()
         assert res[lanes][2:] == res["1:1"][2:]
+
+
+@pytest.mark.parametrize("lanes", ["1:1", "2:2"])
+def test_searches_with_and_without_a_match_alternate_the_dense_ones_are_regrouped(monkeypatch, oracle, lanes):
+    """A dub: every other search finds nothing (its pattern is the source's own material), so none of its pairs can be excluded and
+    its whole rows are formed by the dense multiply-accumulate -- decided per SEARCH and regrouped into items of their own on the
+    device (dense_search_kernel, dense_repack_kernel); its neighbours in every item of the plan keep the pair-by-pair kernels.
+    Results are the bits of a run without any exclusion, the pair counts say who took which way, and the oracle agrees."""
+    from sushi_amd import synth
+    from sushi_amd.device import DeviceStream, SearchBatch
+    from sushi_amd.wav import WavStream
+    monkeypatch.setenv("SUSHI_HIP_LANES", lanes)
+    dst, src, offs, lens, wst, npos, planted = _audio_like_job(n_events=48)
+    other = WavStream.from_samples(synth.make_dst_pcm(360.0, 12000, seed=77), 12000, sample_rate=12000, sample_type="float32")
+    n_src = src.data.shape[1]
+    src_row = np.concatenate([src.data[0], other.data[0]])       # the matched patterns' material, then material of its own
+    dst_row = dst.data[0]
+    matched = [k % 2 == 0 for k in range(len(offs))]
+    offs = [o if has else n_src + o for o, has in zip(offs, matched)]
+    lens[5] = 100000; lens[6] = 90000                            # (two long patterns, one of each kind: mac_long_kernel's list)
+    offs[5] = min(offs[5], src_row.shape[0] - lens[5]); offs[6] = min(offs[6], n_src - lens[6])
+    npos[5] = min(npos[5], dst_row.shape[0] - wst[5] - lens[5] + 1); npos[6] = min(npos[6], dst_row.shape[0] - wst[6] - lens[6] + 1)
+    ref = SearchBatch(DeviceStream(dst_row), DeviceStream(src_row), offs, lens, wst, npos, path="fft", exclusion="never")
+    ref.run()
+    ridx, rscore = ref.results()
+    b = SearchBatch(DeviceStream(dst_row), DeviceStream(src_row), offs, lens, wst, npos, path="fft", exclusion="band")
+    for r in range(3):
+        b.run()
+        idx, score = b.results()
+        assert (idx == ridx).all() and (score.view(np.uint32) == rscore.view(np.uint32)).all(), r
+    d = b.diagnostics()
+    assert d["all_positions"] == 0 and d["slb_violations"] == 0 and d["band"] == 1
+    # the unmatched half lists (nearly) all of its pairs, the matched half next to none
+    assert 0.42 * b.fft_pairs < d["pairs_transformed"] < 0.62 * b.fft_pairs, (d, b.fft_pairs)
+    for k in range(len(offs)):
+        if matched[k] and k != 6:
+            assert abs(int(idx[k]) - planted[k]) <= 1, k
+    for k in (1, 5, 6, 22, 33):
+        ko, so, row = _oracle(oracle, dst_row, src_row, offs[k], lens[k], wst[k], npos[k])
+        assert int(idx[k]) == ko or abs(float(row[int(idx[k])]) - so) <= 2.5e-7
+        assert abs(float(score[k]) - so) <= 1e-4 * so + 2.5e-7
