@@ -538,3 +538,32 @@ def test_searches_with_and_without_a_match_alternate_the_dense_ones_are_regroupe
         ko, so, row = _oracle(oracle, dst_row, src_row, offs[k], lens[k], wst[k], npos[k])
         assert int(idx[k]) == ko or abs(float(row[int(idx[k])]) - so) <= 2.5e-7
         assert abs(float(score[k]) - so) <= 1e-4 * so + 2.5e-7
+
+
+def test_lanes_under_a_workspace_cap_that_one_sub_batch_does_not_fit(monkeypatch):
+    """The lanes need a workspace per LANE, not one for the whole batch: a cap below what one sub-batch for everything needs still
+    gets them, and the cut without lanes that the whole-row runs take is then as few sub-batches as fit the cap, one after the other."""
+    from sushi_amd import _native
+    from sushi_amd.device import SearchBatch
+    dst, src, offs, lens, wst, npos, planted = _audio_like_job(n_events=64)
+    monkeypatch.setenv("SUSHI_HIP_LANES", "1:1")
+    one = SearchBatch(dst.device_stream(), src.device_stream(), offs, lens, wst, npos, path="fft")
+    one.run()
+    idx, score = one.results()
+    ref = (idx.copy(), score.copy().view(np.uint32))
+    monkeypatch.setenv("SUSHI_HIP_LANES", "4:2")
+    cap = int(one.ws_bytes * 0.6)
+    b = SearchBatch(dst.device_stream(), src.device_stream(), offs, lens, wst, npos, path="fft", workspace_bytes=cap)
+    assert b.sub_batches == 4 and b.lanes == 2 and b.ws_bytes <= cap
+    for form in ("band", "never", "whole", "band"):
+        _native.check(_native.lib().sushi_hip_batch_set_exclusion(b.handle, _native.EXCLUSION[form]), "set_exclusion")
+        for r in range(2):
+            b.run()
+            idx, score = b.results()
+            assert (idx == ref[0]).all() and (score.view(np.uint32) == ref[1]).all(), (form, r)
+    # and a cap that not even the lanes fit: sub-batches one after the other, as ever
+    tiny = SearchBatch(dst.device_stream(), src.device_stream(), offs, lens, wst, npos, path="fft", workspace_bytes=int(one.ws_bytes * 0.2))
+    assert tiny.lanes == 1 and tiny.sub_batches >= 5
+    tiny.run()
+    idx, score = tiny.results()
+    assert (idx == ref[0]).all() and (score.view(np.uint32) == ref[1]).all()
