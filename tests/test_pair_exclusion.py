@@ -567,3 +567,29 @@ def test_lanes_under_a_workspace_cap_that_one_sub_batch_does_not_fit(monkeypatch
     tiny.run()
     idx, score = tiny.results()
     assert (idx == ref[0]).all() and (score.view(np.uint32) == ref[1]).all()
+
+
+def test_a_batch_of_a_few_hundred_searches_takes_two_lanes_by_itself(monkeypatch):
+    """No SUSHI_HIP_LANES in the environment: 128 searches and 24 k block pairs are where the library cuts a batch in two halves on
+    two lanes by itself (choose_lanes); same bits as the one-sub-batch run, in AUTO (what a caller gets) as in ALWAYS."""
+    from sushi_amd.device import SearchBatch
+    monkeypatch.delenv("SUSHI_HIP_LANES", raising=False)
+    dst, src, offs, lens, wst, npos, planted = _audio_like_job(n_events=160, seconds=900.0, window=180.0)
+    res = {}
+    for excl in ("auto", "always"):
+        b = SearchBatch(dst.device_stream(), src.device_stream(), offs, lens, wst, npos, path="fft", exclusion=excl)
+        assert b.fft_pairs >= 24 * 1024 and (b.sub_batches, b.lanes) == (2, 2), (b.fft_pairs, b.sub_batches, b.lanes)
+        for r in range(3):
+            b.run()
+            idx, score = b.results()
+        d = b.diagnostics()
+        assert d["band"] == 1 and d["suspended"] == 0 and d["pairs_transformed"] < b.fft_pairs // 10, d
+        res[excl] = (idx.copy(), score.copy().view(np.uint32))
+    monkeypatch.setenv("SUSHI_HIP_LANES", "1:1")
+    one = SearchBatch(dst.device_stream(), src.device_stream(), offs, lens, wst, npos, path="fft", exclusion="always")
+    assert (one.sub_batches, one.lanes) == (1, 1)
+    one.run()
+    idx, score = one.results()
+    for excl in res:
+        assert (res[excl][0] == idx).all() and (res[excl][1] == score.view(np.uint32)).all(), excl
+    assert all(abs(int(i) - p) <= 1 for i, p in zip(idx, planted))
