@@ -58,6 +58,7 @@
 #include <algorithm>
 #include <memory>
 #include <new>
+#include <string>
 #include <type_traits>
 #include <vector>
 
@@ -197,6 +198,18 @@ int sushi_hip_stream_add_spectra(SushiHipStream* s, void* mem_dev, size_t mem_by
     return SUSHI_HIP_OK;
 }
 
+// A caller sizes a batch (sushi_hip_batch_bytes) and then creates it from the same requests: the plan made for the first call is
+// kept for the second (per host thread; compared request by request, so a changed request list simply plans again).
+struct PlanCache {
+    bool valid = false;
+    size_t cap = 0;
+    std::string lanes_env;
+    std::vector<SushiHipRequest> req;
+    Plan plan;
+};
+static thread_local PlanCache g_plan_cache;
+static std::string lanes_env_now() { const char* e = getenv("SUSHI_HIP_LANES"); return e ? std::string(e) : std::string(); }
+
 size_t sushi_hip_batch_bytes(const SushiHipRequest* req_host, int n, int path, int variant, size_t workspace_cap_bytes) try {
     if (!req_host || n <= 0 || (path != SUSHI_HIP_PATH_FFT && path != SUSHI_HIP_PATH_DIRECT)) return 0;
     if (path == SUSHI_HIP_PATH_FFT) variant = direct_variant_count() - 1;
@@ -208,7 +221,12 @@ size_t sushi_hip_batch_bytes(const SushiHipRequest* req_host, int n, int path, i
     if (path == SUSHI_HIP_PATH_DIRECT) return batch_layout(n, path, 0, 0, 0, 0, 0).total;
     Plan plan;
     if (make_plan(descs, workspace_cap_bytes, plan) != SUSHI_HIP_OK) return 0;
-    return batch_layout(n, path, plan.order.size(), plan.items.size(), plan.ws_bytes, plan.subs.size(), plan.segs).total;
+    const size_t total = batch_layout(n, path, plan.order.size(), plan.items.size(), plan.ws_bytes, plan.subs.size(), plan.segs).total;
+    PlanCache& pc = g_plan_cache;
+    pc.valid = true; pc.cap = workspace_cap_bytes; pc.lanes_env = lanes_env_now();
+    pc.req.assign(req_host, req_host + n);
+    pc.plan = std::move(plan);
+    return total;
 } catch (...) { return 0; }        // std::bad_alloc etc.: nothing crosses the C boundary
 
 // requests -> descriptors, plan and layout of `b` (all three replaced together or not at all), uploaded on `st`.
@@ -228,8 +246,15 @@ static int plan_and_upload(SushiHipBatch* b, const SushiHipRequest* req_host, in
     }
     Plan plan;
     if (b->path == SUSHI_HIP_PATH_FFT) {
-        rc = make_plan(descs, b->ws_cap, plan);
-        if (rc != SUSHI_HIP_OK) return rc;
+        PlanCache& pc = g_plan_cache;
+        if (pc.valid && pc.cap == b->ws_cap && (int)pc.req.size() == n && memcmp(pc.req.data(), req_host, (size_t)n * sizeof(SushiHipRequest)) == 0 &&
+            pc.lanes_env == lanes_env_now()) {
+            plan = std::move(pc.plan);                      // (the plan sushi_hip_batch_bytes made for these very requests)
+            pc.valid = false;
+        } else {
+            rc = make_plan(descs, b->ws_cap, plan);
+            if (rc != SUSHI_HIP_OK) return rc;
+        }
     }
     const BatchLayout lay = batch_layout(n, b->path, plan.order.size(), plan.items.size(), plan.ws_bytes, plan.subs.size(), plan.segs);
     if (b->mem_bytes < lay.total) return SUSHI_HIP_ENOSPACE;
