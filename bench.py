@@ -513,8 +513,11 @@ def main():
 
     # one untimed verification pass before anything is timed: a batch that does not recover the planted offset is
     # not worth measuring (it also pages the kernels in; the W warm-up steps below are the contract's)
+    sync()
+    t_first = time.perf_counter()
     v_idx, _ = step()
     sync()
+    first_step_ms = (time.perf_counter() - t_first) * 1e3          # the batch's FIRST run: what a one-shot job's only step is
     v_idx = v_idx.cpu().numpy()
     v_times = np.array(start_times) + v_idx.astype(np.float64) / float(rate)
     v_err = np.abs((v_times - ev_starts) - args.offset) * rate
@@ -826,9 +829,15 @@ def main():
             # `value` is a RESIDENT-STATE rate (streams, spectra, plan and workspace in HBM, the same job every step).  What a
             # one-shot job -- sushi.py:663-672: two WavStream loads, then one calculate_shifts pass -- gets from this process:
             # events / (set-up + one step), with the process's start-up behind it -- and with the start-up on the critical path
-            "one_shot_events_per_s": None if not setup_ms else n_total / ((sum(setup_ms.values()) + elapsed / args.steps * 1e3) * 1e-3),
+            # (its ONE step is the batch's first run -- the exclusion's form is voted on, nothing is warm --: `first_step_ms`, wall
+            # clock around the untimed verification pass; until round 6's last day these two figures took a steady-state step instead,
+            # which a first run was 9 - 13 ms away from: the vote's same-address atomics, the lanes' streams made inside the run)
+            "first_step_ms": first_step_ms,
+            "one_shot_events_per_s": None if not setup_ms else n_total / ((sum(setup_ms.values()) + first_step_ms) * 1e-3),
             "one_shot_incl_process_start_events_per_s": None if not setup_ms else
-                n_total / ((process_start_ms + sum(setup_ms.values()) + elapsed / args.steps * 1e3) * 1e-3),
+                n_total / ((process_start_ms + sum(setup_ms.values()) + first_step_ms) * 1e-3),
+            "one_shot_with_a_steady_state_step_events_per_s": None if not setup_ms else
+                n_total / ((sum(setup_ms.values()) + elapsed / args.steps * 1e3) * 1e-3),
         }
         if dry:
             out["dry_run"] = "control flow only (--dry-backend %s): `value` is not a measurement" % args.dry_backend

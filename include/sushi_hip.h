@@ -75,6 +75,10 @@ SUSHI_HIP_API const char* sushi_hip_strerror(int code);
 
 /* 0 if a gfx950 device is current, SUSHI_HIP_ENODEV otherwise. */
 SUSHI_HIP_API int sushi_hip_device_ok(void);
+/* What a batch's first run would otherwise create on the current device, made NOW (v13): the HIP streams the lanes of large batches
+ * run on (a stream is a hardware queue: ~5 ms each) and the pinned words a run's counts come back through.  Optional -- a process
+ * that calls it while it is busy elsewhere (sushi_amd.device.warm_up does, behind the demux) takes 11 ms off its first large batch. */
+SUSHI_HIP_API int sushi_hip_device_prepare(void);
 
 /* ---- streams --------------------------------------------------------------------------------------------
  * raw_dev: the n samples of the row WavStream.data[0] (`dtype`), already in HBM; they stay the caller's and

@@ -92,6 +92,7 @@ def lib():
     L.sushi_hip_strerror.restype = ctypes.c_char_p
     L.sushi_hip_strerror.argtypes = [ci]
     L.sushi_hip_device_ok.restype = ci
+    L.sushi_hip_device_prepare.restype = ci
     L.sushi_hip_fft_size.restype = ci
     L.sushi_hip_fft_block.restype = ci
     L.sushi_hip_fft_slot_of_bin.restype = ci

@@ -57,6 +57,7 @@
 
 #include <algorithm>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -91,6 +92,49 @@ constexpr int LDS_FLOATS = sushi_fft::lds_floats<FFT_LOGN>();
 #include "sushi_fft_plan.inc"
 
 }  // namespace
+
+// What a batch's FIRST run used to allocate -- 16 bytes of pinned host memory for the counts that come back behind an event, the
+// lanes' HIP streams -- cost that run 9 - 13 ms of host time (hipHostMalloc maps into every device's page tables; a stream is a
+// hardware queue): both now come from pools of the process's own, made once (tools/first_run_probe.py: the first run of a batch of
+// BASELINE configs[2] spent 9.4 of its 21.6 ms inside sushi_hip_batch_run on the host).  Pool slots are handed out under a mutex; a handle is used by one host thread at a time.
+struct HostSlots {
+    static constexpr int SLOTS = 1024, WORDS = 2;
+    std::mutex mu;
+    unsigned long long* base = nullptr;
+    std::vector<int> free_list;
+    unsigned long long* take() {
+        std::lock_guard<std::mutex> g(mu);
+        if (!base) {
+            if (hipHostMalloc((void**)&base, (size_t)SLOTS * WORDS * sizeof(unsigned long long), hipHostMallocPortable) != hipSuccess) { base = nullptr; return nullptr; }
+            for (int k = SLOTS - 1; k >= 0; --k) free_list.push_back(k);
+        }
+        if (free_list.empty()) return nullptr;
+        const int k = free_list.back(); free_list.pop_back();
+        return base + (size_t)k * WORDS;
+    }
+    void give(unsigned long long* p) {
+        if (!p) return;
+        std::lock_guard<std::mutex> g(mu);
+        free_list.push_back((int)((p - base) / WORDS));
+    }
+};
+static HostSlots g_host_slots;
+
+// The lanes' streams, per device: shared by every batch on that device (batches that run at the same time on different caller
+// streams then share them too -- ordered by their own events, side by side no longer; one batch at a time is the product's use).
+struct LanePool {
+    static constexpr int MAX_DEVICES = 16;
+    std::mutex mu;
+    hipStream_t st[MAX_DEVICES][MAX_LANES] = {};
+    hipStream_t get(int lane) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
+        std::lock_guard<std::mutex> g(mu);
+        if (!st[dev][lane] && hipStreamCreateWithFlags(&st[dev][lane], hipStreamNonBlocking) != hipSuccess) st[dev][lane] = nullptr;
+        return st[dev][lane];
+    }
+};
+static LanePool g_lane_pool;
 
 // The opaque batch handle of the C ABI.
 struct SushiHipBatch {
@@ -136,18 +180,27 @@ struct SushiHipBatch {
     hipEvent_t fork;
     ~SushiHipBatch() {
         for (int l = 1; l < MAX_LANES; ++l) {
-            if (lane_stream[l]) { (void)hipStreamSynchronize(lane_stream[l]); (void)hipStreamDestroy(lane_stream[l]); }
+            if (lane_stream[l]) (void)hipStreamSynchronize(lane_stream[l]);          // (the pool's: this batch's work on it has to be through)
             if (lane_done[l]) (void)hipEventDestroy(lane_done[l]);
         }
         if (fork) (void)hipEventDestroy(fork);
         if (uploaded) { (void)hipEventSynchronize(uploaded); (void)hipEventDestroy(uploaded); }    // (an upload may still read the handle's host buffers)
         if (stats_pending && stats_ready) (void)hipEventSynchronize(stats_ready);       // the last run's counts may still be on their way
         if (stats_ready) (void)hipEventDestroy(stats_ready);
-        if (host_stats) (void)hipHostFree(host_stats);
+        g_host_slots.give(host_stats);
     }
 };
 
 extern "C" {
+
+int sushi_hip_device_prepare(void) {
+    for (int l = 1; l < MAX_LANES; ++l)
+        if (!g_lane_pool.get(l)) return SUSHI_HIP_ELAUNCH;
+    unsigned long long* p = g_host_slots.take();
+    if (!p) return SUSHI_HIP_ENOMEM;
+    g_host_slots.give(p);
+    return SUSHI_HIP_OK;
+}
 
 int sushi_hip_fft_size(void) { return FN; }
 
@@ -472,7 +525,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         for (int l = 1; l < lanes; ++l) {
             // (stream priorities for the lanes -- the batch's own below the caller's, above it, one of each -- and an occupancy cap on
             // mac_kernel<1024> were measured flat: 8.31 - 8.55 ms whatever the setting, tools/experiments/README.md)
-            if (!b->lane_stream[l] && hipStreamCreateWithFlags(&b->lane_stream[l], hipStreamNonBlocking) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+            if (!b->lane_stream[l] && !(b->lane_stream[l] = g_lane_pool.get(l))) return SUSHI_HIP_ELAUNCH;
             if (!b->lane_done[l] && hipEventCreateWithFlags(&b->lane_done[l], hipEventDisableTiming) != hipSuccess) return SUSHI_HIP_ELAUNCH;
             if (hipStreamWaitEvent(b->lane_stream[l], b->fork, 0) != hipSuccess) return SUSHI_HIP_ELAUNCH;
             lane_st[l] = b->lane_stream[l];
@@ -526,7 +579,8 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         ba.slist = (int*)(wsp + wl.slist); ba.scount = scount; ba.order = order + sbt.order_first;
         ba.gkeys = gkeys; ba.pair_lb = pair_lb; ba.counters = counters;
         ba.acc = (float*)(wsp + wl.acc);
-        ba.sub_first_seg = sbt.first_seg; ba.tnorm_rest = tnorm_rest; ba.znorm_rest = dst->znorm_rest; ba.norm_stride = dst->norm_stride; ba.band_votes = scount + 2;
+        ba.sub_first_seg = sbt.first_seg; ba.tnorm_rest = tnorm_rest; ba.znorm_rest = dst->znorm_rest; ba.norm_stride = dst->norm_stride;
+        ba.band_votes = (int*)(wsp + wl.votes);
         ba.audit_mark = (unsigned char*)(wsp + wl.audit_mark); ba.audit_seq = run_seq; ba.audit_every = b->audit_every;
         // What a packed-half transform output (bound_low_kernel / bound_kernel) may be off by, in units of the largest pass-1 value:
         // every output is a sum of 64 pass-1 values through ROUNDING LEVELS of 2^-11 each -- a level at which the partial sums hold m
@@ -555,13 +609,17 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
             else if (b->exclusion == SUSHI_HIP_EXCLUDE_WHOLE) band = 0;
             else {
                 if (b->band < 0 || b->band_decided_method != b->method) {
-                    if (hipMemsetAsync(scount + 2, 0, 2 * sizeof(int), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
+                    static_assert(VOTE_SLOTS * VOTE_STRIDE == 64 * 32, "ws_layout keeps room for the prediction's counters");
+                    int slots[VOTE_SLOTS * VOTE_STRIDE];
+                    if (hipMemsetAsync(ba.band_votes, 0, sizeof(slots), st) != hipSuccess) return SUSHI_HIP_ELAUNCH;
                     BoundArgs bp = ba;
                     bp.band = 2;
                     if (launch_slb(bp) != SUSHI_HIP_OK) return SUSHI_HIP_ELAUNCH;
-                    if (hipMemcpyAsync(b->band_votes, scount + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    if (hipMemcpyAsync(slots, ba.band_votes, sizeof(slots), hipMemcpyDeviceToHost, st) != hipSuccess ||
                         hipStreamSynchronize(st) != hipSuccess)
                         return SUSHI_HIP_ELAUNCH;
+                    b->band_votes[0] = b->band_votes[1] = 0;
+                    for (int v = 0; v < VOTE_SLOTS; ++v) { b->band_votes[0] += slots[v * VOTE_STRIDE]; b->band_votes[1] += slots[v * VOTE_STRIDE + 1]; }
                     // (measured at BASELINE configs[2]: 97 % of the pairs vote for it at 12 dB of noise on the source -- 9.7 ms against 17.5 for
                     // the whole-row form --, 87 % at 6 dB -- 12.5 against 17.5 --, 14 % at 0 dB -- 28.7 against 18.7)
                     b->band = b->band_votes[0] > 0 && (double)b->band_votes[1] >= 0.75 * (double)b->band_votes[0] ? 1 : 0;
@@ -778,7 +836,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
     prof_end(pc, t0, SUSHI_HIP_STAGE_FINISH, st0);
     if (rc == SUSHI_HIP_OK && excluded_any && !b->stats_pending) {
         // what this run's exclusion left, for the runs after it (never waited for: the event is queried)
-        if (!b->host_stats && hipHostMalloc((void**)&b->host_stats, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) b->host_stats = nullptr;
+        if (!b->host_stats) b->host_stats = g_host_slots.take();                 // (none left: this batch's AUTO does not learn)
         if (b->host_stats && !b->stats_ready && hipEventCreateWithFlags(&b->stats_ready, hipEventDisableTiming) != hipSuccess) b->stats_ready = nullptr;
         if (b->host_stats && b->stats_ready &&
             hipMemcpyAsync(b->host_stats, &counters->pairs_transformed, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st0) == hipSuccess &&

@@ -58,6 +58,9 @@ def warm_up(device=None, background=False):
                     with torch.cuda.device(dev):
                         tiny = DeviceStream(np.linspace(0.0, 1.0, 65536, dtype=np.float32), device=dev, _wait_for_warm_up=False)
                         tiny.searchable()
+                        # the lanes' HIP streams and the pinned words a run's counts come back through (a large batch's first run
+                        # made them itself: 11 ms of it)
+                        _native.check(_native.lib().sushi_hip_device_prepare(), "sushi_hip_device_prepare")
                         torch.cuda.synchronize(dev)
                 except Exception as e:                  # (the real call that follows raises the same, where it can be handled)
                     w["error"] = e
