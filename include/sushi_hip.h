@@ -39,8 +39,8 @@ extern "C" {
                                      default), the band is |f| < N/8 strictly (bin 7N/8 of a low row is zero and counted with the rest), sushi_hip_batch_reset,
                                      sushi_hip_batch_workspace_view, SUSHI_HIP_ENOMEM / _EINTERNAL;
                                      13: SushiHipBatchInfo.lanes (appended): a large batch's sub-batches run side by side on HIP streams
-                                     of the batch's own, forked off and joined back into the stream a run is given;
-                                     sushi_hip_batch_set_early_output */
+                                     of the library's own, forked off and joined back into the stream a run is given;
+                                     sushi_hip_batch_set_early_output, sushi_hip_device_prepare */
 
 #if defined(__GNUC__)
 #define SUSHI_HIP_API __attribute__((visibility("default")))
@@ -158,8 +158,9 @@ typedef struct SushiHipBatchInfo {
     double flops;             /* 2 * P * M summed over the requests (the direct form's work) */
     double algorithmic_bytes; /* every search and pattern sample once + 8 bytes out per request */
     int32_t lanes;            /* FFT path: HIP streams the sub-batches of a run are spread over (1: all on the stream the run is given).
-                                 Lane 0 IS that stream; the others belong to the batch, start behind the run's first launch and are
-                                 joined before its last, so the caller sees one stream's ordering.  The stages of the path are bound by
+                                 Lane 0 IS that stream; the others are the library's own (one set per device, made by the first run
+                                 that needs them or by sushi_hip_device_prepare), start behind the run's first launch and are joined
+                                 before its last, so the caller sees one stream's ordering.  The stages of the path are bound by
                                  different things (stores, instruction issue, LDS, HBM reads): side by side they fill each other's gaps.
                                  SUSHI_HIP_LANES="subs:lanes" in the environment when the batch is created overrides the choice. */
     int32_t reserved;
@@ -268,7 +269,7 @@ SUSHI_HIP_API int sushi_hip_batch_set_early_output(SushiHipBatch* batch, int32_t
  * method changed) that goes through the pair exclusion in AUTO or ALWAYS mode reads 8 bytes back to decide the exclusion's form and
  * synchronises `hip_stream` once for that (not capturable in a hipGraph; BAND, WHOLE and NEVER never synchronise, nor does a
  * batch too small for AUTO to use the exclusion -- a drop-in find_substream call).  Environment variables are read when a batch is
- * created, never here.  A batch on lanes (SushiHipBatchInfo.lanes > 1) launches its sub-batches on streams of its own between the
+ * created, never here.  A batch on lanes (SushiHipBatchInfo.lanes > 1) launches its sub-batches on streams of the library's own between the
  * run's first launch and its last on `hip_stream`: what is ordered behind the run on `hip_stream` is ordered behind all of it.  The
  * first run of such a batch that forms whole rows for every pair (whole-row form, no exclusion) builds the plan's one-sub-batch
  * cut on the host first (milliseconds, once).
