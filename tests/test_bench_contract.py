@@ -75,3 +75,11 @@ def test_pmc_traffic_of_every_bench_workload_is_current():
         assert k["fetch_bytes"] > 0 and k["write_bytes"] > 0 and k["write_source"] == "WRITE_SIZE"
         # (every one of these workloads takes the band-split form of the exclusion: its bound pass is bound_low_kernel)
         assert e["kernels"]["bound_low_kernel"]["fetch_bytes"] > 0 and e["kernels"]["mac_list_kernel"]["fetch_bytes"] > 0
+
+
+def test_design_table_is_the_committed_evidence():
+    """DESIGN.md's round-6 numbers table is generated from profiles/r06/final/bench_*_n1.json (tools/design_table.py): a table that
+    differs from what the committed bench lines say fails here."""
+    import subprocess
+    import sys
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "design_table.py"), "--check"]) == 0
