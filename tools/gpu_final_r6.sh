@@ -51,7 +51,7 @@ timeout 1200 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 
 fi
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.log
 timeout 60 python tools/kernel_resources.py sushi_fft > $O/kernel_resources_fft.txt 2>&1
-timeout 60 python tools/kernel_resources.py sushi_hip > $O/kernel_resources_hip.txt 2>&1
+timeout 400 python tools/kernel_resources.py sushi_hip > $O/kernel_resources_hip.txt 2>&1
 timeout 120 python tools/latency.py > $O/latency.json 2> $O/latency.err
 timeout 120 python tools/call_breakdown.py > $O/call_breakdown.json 2> $O/call_breakdown.err
 if [ "$WITH_HUNTS" = 1 ]; then
