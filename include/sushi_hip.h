@@ -189,11 +189,13 @@ typedef struct SushiHipBatchDiag {
     float max_slb_ratio_excluded; /* max over the audited excluded pairs of (the pair's lower bound) / (an upper bound of the exact
                                  score of its best position); < 1 or the search went to all_positions */
     int32_t slb_violations;   /* transformed pairs (audited or not) whose lower bound was found above a real score: 0 */
-    int32_t band;             /* form of the exclusion the last run used: 0 whole rows, 1 band-split, -1 none */
+    int32_t band;             /* form of the exclusion the last run used (its last sub-batch that went through it): 0 whole rows,
+                                 1 band-split, -1 none */
     int32_t suspended;        /* 1: AUTO left the exclusion out of the last run -- an earlier run of this batch had excluded next to
                                  nothing (searches without a match anywhere: no bound can help), so the passes that compute the bounds
                                  would only be overhead; every 64th run looks again */
-    int32_t band_votes[2];    /* what AUTO / ALWAYS decided the form from (first run of a batch): block pairs looked at, and those whose
+    int32_t band_votes[2];    /* what AUTO / ALWAYS decided the form from (first run of a batch): block pairs looked at (all of them; those of
+                                 the first sub-batch where there are several), and those whose
                                  bound -- with nothing but the rows' norms outside the band -- already leaves room to exclude; the
                                  band-split form is taken when that is >= 75 % */
     int64_t second_look_audited; /* of excluded_audited: pairs the FIRST bound had let through and the second look (band-split form:

@@ -147,7 +147,7 @@ struct SushiHipBatch {
     unsigned run_seq;                   // runs so far: rotates which excluded pairs are audited
     int audit_every;                    // one search in this many has one excluded pair transformed as a check, per run
     int bound_model;                    // SUSHI_HIP_BOUND_WORST_CASE (default) / _STATISTICAL: how the excluded side's roundings enter slb
-    int last_band;                      // form of the exclusion the last run's last sub-batch used (-1: none)
+    int last_band;                      // form of the exclusion the last run used (its last sub-batch that went through it; -1: none did)
     bool last_whole_cut;                // the last run took the plan's one-sub-batch cut (Plan::subs_whole)
     // AUTO learns from its own runs: a batch whose exclusion excluded next to nothing (searches without a match anywhere) runs
     // without it from then on, looking again every 64th run.  The last run's counts come back through 16 bytes of pinned host memory
@@ -532,6 +532,7 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         }
     }
 
+    b->last_band = -1;                                           // (the form of the last sub-batch of this run that went through the exclusion)
     // Sub-batches of a plan on lanes run side by side (sushi_fft_plan.inc "Lanes"); the others one after the other.
     for (size_t si = 0; si < subs.size(); ++si) {
         const SubBatch& sbt = subs[si];
@@ -601,9 +602,8 @@ int sushi_hip_batch_run(SushiHipBatch* b, double delta, int32_t* out_idx_dev, fl
         // every spectrum and bounds the rest by the rows' norms -- a quarter of the bytes and a third of the instructions, IF the
         // streams keep most of their energy in the band (audio does; white noise does not).  Decided once per batch and method, on
         // the device's own numbers: with nothing at all from the low band, does the rest alone leave the bound room to exclude?
-        // (One small kernel over the first sub-batch's pairs and one 8-byte read-back, in the first run only.)
+        // (One small kernel over the first excluded sub-batch's pairs and one 8 KB read-back, in the first run only.)
         int band = 0;
-        b->last_band = -1;
         if (exclude) {
             if (b->exclusion == SUSHI_HIP_EXCLUDE_BAND) band = 1;
             else if (b->exclusion == SUSHI_HIP_EXCLUDE_WHOLE) band = 0;

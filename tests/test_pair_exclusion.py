@@ -55,7 +55,9 @@ def test_almost_every_pair_is_excluded_and_the_results_are_the_oracles(oracle, m
     assert d["all_positions"] == 0 and d["max_bound_ratio"] < 1.0 and d["max_bound_ratio_noncandidate"] < 1.0
     # the form: forced, or -- 'always' -- chosen from the streams' own norms outside the band: low-passed material takes the band-split form
     if form == "always":
-        assert d["band_votes"][0] == b.fft_pairs and d["band"] == (1 if d["band_votes"][1] >= 0.75 * d["band_votes"][0] else 0), d
+        # (votes: every pair of the batch, or of its first sub-batch where SUSHI_HIP_LANES cuts even this one)
+        assert (d["band_votes"][0] == b.fft_pairs if b.sub_batches == 1 else 0 < d["band_votes"][0] < b.fft_pairs), d
+        assert d["band"] == (1 if d["band_votes"][1] >= 0.75 * d["band_votes"][0] else 0), d
     else:
         assert d["band"] == {"band": 1, "whole": 0}[form], d
     # the audit of the exclusion: per run one excluded pair of every second search is transformed all the same and its lower
